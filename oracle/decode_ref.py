@@ -1,0 +1,197 @@
+"""ORACLE (test infrastructure, never on the product path): numpy restatement of the
+decode half of the reference inference path - anchors, box / translation decode,
+detection filter (score threshold -> greedy NMS -> top-k -> pad), the evaluate.py
+post-filter, and the ADD / ADD-S pose metrics.
+
+PINNED: anchors against the reference's own fixtures ``onnx-models/anchors_256.txt``,
+``translation_anchors_{256,512}.txt`` (bit-exact, tests/golden/anchors_*.npz);
+box/translation decode against outputs of the imported reference
+(tests/golden/make_golden.py).  NMS / top-k follow TensorFlow semantics that cannot
+be executed here (TensorFlow is absent from the reference tree and this image):
+**parity unpinned** for ties; the convention is stated in ``nms_greedy``.
+"""
+from __future__ import annotations
+
+import math
+from typing import Tuple
+
+import numpy as np
+
+SIZES = (32, 64, 128, 256, 512)
+STRIDES = (8, 16, 32, 64, 128)
+LEVELS = (3, 4, 5, 6, 7)
+# stored as float32, used in float64 arithmetic (generators/utils/anchors.py:59-66)
+RATIOS = np.array([1, 0.5, 2], dtype=np.float32)
+SCALES = np.array([2 ** 0, 2 ** (1.0 / 3.0), 2 ** (2.0 / 3.0)], dtype=np.float32)
+
+
+def base_anchors(base_size: int) -> np.ndarray:
+    """generate_anchors, generators/utils/anchors.py:385-419: 9 boxes centred on 0,
+    ordered scale-major (s0r0, s0r1, s0r2, s1r0, ...), float64."""
+    n = len(RATIOS) * len(SCALES)
+    a = np.zeros((n, 4))
+    a[:, 2:] = base_size * np.tile(np.repeat(SCALES, len(RATIOS))[None], (2, 1)).T
+    areas = a[:, 2] * a[:, 3]
+    a[:, 2] = np.sqrt(areas / np.tile(RATIOS, len(SCALES)))
+    a[:, 3] = a[:, 2] * np.tile(RATIOS, len(SCALES))
+    a[:, 0::2] -= np.tile(a[:, 2] * 0.5, (2, 1)).T
+    a[:, 1::2] -= np.tile(a[:, 3] * 0.5, (2, 1)).T
+    return a
+
+
+def anchors_for_size(size: int) -> Tuple[np.ndarray, np.ndarray]:
+    """anchors_for_shape((size,size)), anchors.py:273-318 with shift (:321-347) and
+    translation_shift (:350-382): cells row-major (y outer), centres (i+0.5)*stride,
+    float64 math, one final cast to float32.  Returns (N,4) x1y1x2y2 and (N,3) cx,cy,stride."""
+    boxes, trans = [], []
+    for lvl, base, stride in zip(LEVELS, SIZES, STRIDES):
+        fm = (size + 2 ** lvl - 1) // (2 ** lvl)                      # guess_shapes :257-270
+        c = (np.arange(0, fm) + 0.5) * stride
+        sx, sy = np.meshgrid(c, c)
+        shifts = np.stack([sx.ravel(), sy.ravel(), sx.ravel(), sy.ravel()], axis=1)   # (K,4)
+        b = (base_anchors(base)[None, :, :] + shifts[:, None, :]).reshape(-1, 4)
+        t = np.concatenate([np.repeat(shifts[:, :2], 9, axis=0), np.full((fm * fm * 9, 1), float(stride))], axis=1)
+        boxes.append(b)
+        trans.append(t)
+    return np.concatenate(boxes).astype(np.float32), np.concatenate(trans).astype(np.float32)
+
+
+def decode_boxes(anchors: np.ndarray, regression: np.ndarray, size: int) -> np.ndarray:
+    """format_bboxes, hmdegopose/loss.py:12-23 -> bbox_transform_inv layers.py:169-200 ->
+    ClipBoxes layers.py:117-136.  float32 arithmetic like the torch original; deltas are
+    ordered (ty, tx, th, tw); output (xmin, ymin, xmax, ymax) clipped to [0, size-1]."""
+    a = anchors.astype(np.float32)[None]
+    d = regression.astype(np.float32)
+    two = np.float32(2)
+    cxa = (a[..., 0] + a[..., 2]) / two
+    cya = (a[..., 1] + a[..., 3]) / two
+    wa = a[..., 2] - a[..., 0]
+    ha = a[..., 3] - a[..., 1]
+    ty, tx, th, tw = d[..., 0], d[..., 1], d[..., 2], d[..., 3]
+    with np.errstate(over="ignore"):
+        w = np.exp(tw) * wa
+        h = np.exp(th) * ha
+    cy = ty * ha + cya
+    cx = tx * wa + cxa
+    out = np.stack([cx - w / two, cy - h / two, cx + w / two, cy + h / two], axis=-1)
+    return np.clip(out, np.float32(0), np.float32(size - 1)).astype(np.float32)
+
+
+def decode_translation(t_anchors: np.ndarray, raw: np.ndarray, cam: np.ndarray) -> np.ndarray:
+    """format_translation, loss.py:30-51 -> translation_transform_inv layers.py:142-166 ->
+    CalculateTxTy layers.py:203-249.  cam[B,6] = fx, fy, px, py, tz_scale, image_scale."""
+    ta = t_anchors.astype(np.float32)[None]
+    r = raw.astype(np.float32)
+    cam = cam.astype(np.float32)
+    stride = ta[..., 2]
+    x = ta[..., 0] + r[..., 0] * stride
+    y = ta[..., 1] + r[..., 1] * stride
+    fx, fy, px, py, tzs, isc = (cam[:, i][:, None] for i in range(6))
+    x = x / isc - px
+    y = y / isc - py
+    tz = r[..., 2] * tzs
+    return np.stack([x * tz / fx, y * tz / fy, tz], axis=-1).astype(np.float32)
+
+
+def iou_xyxy(a: np.ndarray, b: np.ndarray) -> np.float32:
+    """IoU as TensorFlow's non_max_suppression computes it: plain areas, no '+1' pixel
+    convention, float32; degenerate (area<=0) boxes give 0."""
+    f = np.float32
+    ax0, ay0, ax1, ay1 = (f(min(a[0], a[2])), f(min(a[1], a[3])), f(max(a[0], a[2])), f(max(a[1], a[3])))
+    bx0, by0, bx1, by1 = (f(min(b[0], b[2])), f(min(b[1], b[3])), f(max(b[0], b[2])), f(max(b[1], b[3])))
+    aa = f((ax1 - ax0) * (ay1 - ay0))
+    ab = f((bx1 - bx0) * (by1 - by0))
+    if aa <= 0 or ab <= 0:
+        return f(0)
+    iw = f(max(f(min(ax1, bx1) - max(ax0, bx0)), f(0)))
+    ih = f(max(f(min(ay1, by1) - max(ay0, by0)), f(0)))
+    inter = f(iw * ih)
+    return f(inter / f(f(aa + ab) - inter))
+
+
+def nms_greedy(boxes: np.ndarray, scores: np.ndarray, max_out: int, iou_thr: float) -> np.ndarray:
+    """tf.image.non_max_suppression as called at layers.py:332: candidates in descending
+    score order (CONVENTION: equal scores -> lower index first); a candidate is dropped when
+    its IoU with an already kept box is STRICTLY greater than iou_thr; stops at max_out."""
+    order = np.lexsort((np.arange(len(scores)), -scores.astype(np.float64)))
+    keep = []
+    for i in order:
+        ok = True
+        for j in keep:
+            if iou_xyxy(boxes[i], boxes[j]) > np.float32(iou_thr):
+                ok = False
+                break
+        if ok:
+            keep.append(int(i))
+            if len(keep) >= max_out:
+                break
+    return np.asarray(keep, dtype=np.int64)
+
+
+def filter_detections(boxes, classification, rotation, translation, hand,
+                      score_threshold=0.5, max_detections=100, nms_threshold=0.5):
+    """filter_detections, layers.py:264-400, one image, num_classes == 1: indices with
+    score > threshold -> NMS -> top_k (already score-sorted, ties lower index) -> gather ->
+    pad with -1 to max_detections rows.  Returns (boxes[M,4], scores[M], labels[M] int32,
+    rotation[M,3], translation[M,3], hand[M,63], anchor_index[M] int32 (-1 padded))."""
+    s = classification[:, 0].astype(np.float32)
+    cand = np.nonzero(s > np.float32(score_threshold))[0]
+    kept = cand[nms_greedy(boxes[cand], s[cand], max_detections, nms_threshold)] if len(cand) else cand
+    order = np.lexsort((np.arange(len(kept)), -s[kept].astype(np.float64)))[:max_detections]
+    idx = kept[order]
+    n = len(idx)
+
+    def pad(a, w=None):
+        shape = (max_detections,) if w is None else (max_detections, w)
+        out = np.full(shape, -1, dtype=a.dtype)
+        out[:n] = a
+        return out
+
+    return (pad(boxes[idx].astype(np.float32), 4), pad(s[idx]), pad(np.zeros(n, np.int32)),
+            pad(rotation[idx].astype(np.float32), 3), pad(translation[idx].astype(np.float32), 3),
+            pad(hand[idx].astype(np.float32), hand.shape[1]), pad(idx.astype(np.int32)))
+
+
+def post_filter(boxes, scores, rotations, translations, scale: float, score_threshold: float, max_detections: int):
+    """_get_detections, eval/common.py:419-447: boxes/=scale, rotations*=pi, keep score>thr,
+    argsort(-scores)[:max_detections]."""
+    boxes = boxes / np.float32(scale)
+    rotations = rotations * np.float32(math.pi)
+    ind = np.nonzero(scores > score_threshold)[0]
+    order = np.argsort(-scores[ind], kind="stable")[:max_detections]
+    sel = ind[order]
+    return boxes[sel], scores[sel], rotations[sel], translations[sel]
+
+
+def rodrigues(rvec: np.ndarray) -> np.ndarray:
+    """Axis-angle -> rotation matrix (cv2.Rodrigues at colibri_common.py:803-813), float64."""
+    r = np.asarray(rvec, dtype=np.float64).reshape(3)
+    th = np.linalg.norm(r)
+    if th < 1e-12:
+        return np.eye(3)
+    k = r / th
+    K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    return np.eye(3) * math.cos(th) + (1 - math.cos(th)) * np.outer(k, k) + math.sin(th) * K
+
+
+def add_metric(points, diameter, R_gt, t_gt, R_pr, t_pr, thr=0.1):
+    """check_6d_pose_add, eval/common.py:682-710: mean distance over ALL model points."""
+    g = points @ R_gt.T + t_gt
+    p = points @ R_pr.T + t_pr
+    d = float(np.mean(np.linalg.norm(g - p, axis=-1)))
+    return d <= diameter * thr, d
+
+
+def add_s_metric(points, diameter, R_gt, t_gt, R_pr, t_pr, thr=0.1, max_points=1000):
+    """check_6d_pose_add_s, eval/common.py:713-746 + c_min_distances calc_min_distances.h:24-35:
+    step = n//max_points+1 subsampling of both clouds, float32 brute-force nearest distance."""
+    g = (points @ R_gt.T + t_gt)
+    p = (points @ R_pr.T + t_pr)
+    step = points.shape[0] // max_points + 1
+    g = g[::step].astype(np.float32)
+    p = p[::step].astype(np.float32)
+    diff = g[:, None, :] - p[None, :, :]
+    d2 = (diff[..., 0] * diff[..., 0] + diff[..., 1] * diff[..., 1]) + diff[..., 2] * diff[..., 2]
+    dmin = np.sqrt(d2.astype(np.float64)).astype(np.float32).min(axis=1)
+    d = float(np.mean(dmin))
+    return d <= diameter * thr, d

@@ -1,0 +1,219 @@
+"""ORACLE (test infrastructure, never on the product path): fp32 CPU restatement of
+the reference network forward ``HMDEgoPose.forward`` as one functional pass over a
+plain ``state_dict``.
+
+It is a floating-point convolutional network, so the restatement uses
+``torch.nn.functional`` fp32 CPU ops (the tier's "torch fp32 reference for a
+floating-point kernel"); the integer/index half of the path lives in
+``oracle/decode_ref.py`` (numpy).  Written from SURVEY.md section 8a / Appendix C;
+each function cites the reference lines it follows.
+
+PINNED: ``tests/golden/make_golden.py`` imports the real reference in the build
+container, runs both on identical seeded weights/inputs and commits
+slices + sums of every output and of every stage boundary; ``tests/test_oracle_golden.py``
+replays them (tolerance 1e-5 abs on O(1) activations).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Mapping, Tuple
+
+import torch
+import torch.nn.functional as F
+
+BN_EPS = 1e-3
+FUSION_EPS = 1e-4
+NUM_ANCHORS = 9
+
+_SCALING = [(1.0, 1.0), (1.0, 1.1), (1.1, 1.2), (1.2, 1.4), (1.4, 1.8), (1.6, 2.2), (1.8, 2.6), (2.0, 3.1)]
+_BACKBONE_OF_PHI = [0, 1, 2, 3, 4, 5, 6, 6, 7]
+_FPN_REPEATS = [3, 4, 5, 6, 7, 7, 8, 8, 8]
+_HEAD_DEPTH = [3, 3, 3, 4, 4, 4, 5, 5, 5]
+_STAGES = [(1, 3, 1, 1, 32, 16), (2, 3, 2, 6, 16, 24), (2, 5, 2, 6, 24, 40), (3, 3, 2, 6, 40, 80),
+           (3, 5, 1, 6, 80, 112), (4, 5, 2, 6, 112, 192), (1, 3, 1, 6, 192, 320)]
+
+
+def swish(x: torch.Tensor) -> torch.Tensor:
+    """efficientnet/utils.py:57-59 (onnx_export=True everywhere => plain x*sigmoid(x))."""
+    return x * torch.sigmoid(x)
+
+
+def _same_pad(x: torch.Tensor, k: int, s: int) -> torch.Tensor:
+    """Zero padding of efficientnet/utils_extra.py:33-44 (conv) and :72-83 (max-pool):
+    extra=(ceil(n/s)-1)*s-n+k, before=extra//2, after=extra-before; width then height."""
+    h, w = x.shape[-2:]
+    eh = (math.ceil(w / s) - 1) * s - w + k
+    ev = (math.ceil(h / s) - 1) * s - h + k
+    l, t = eh // 2, ev // 2
+    return F.pad(x, [l, eh - l, t, ev - t])
+
+
+def conv_same(x, w, b=None, stride=1, groups=1):
+    """Conv2dStaticSamePadding.forward, efficientnet/utils_extra.py:33-47."""
+    return F.conv2d(_same_pad(x, w.shape[-1], stride), w, b, stride=stride, groups=groups)
+
+
+def maxpool_same(x):
+    """MaxPool2dStaticSamePadding(3, 2).forward, utils_extra.py:72-86: padded with
+    ZEROS (F.pad default), not -inf, so edge windows take max(..., 0)."""
+    return F.max_pool2d(_same_pad(x, 3, 2), 3, 2)
+
+
+def bn(sd: Mapping[str, torch.Tensor], p: str, x: torch.Tensor) -> torch.Tensor:
+    """nn.BatchNorm2d in eval mode, eps 1e-3 (efficientnet/model.py:32-33; efficientdet/model.py:36)."""
+    return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"], sd[p + ".weight"], sd[p + ".bias"],
+                        training=False, eps=BN_EPS)
+
+
+def _round_width(c, mult):
+    c2 = c * mult
+    r = max(8, int(c2 + 4) // 8 * 8)
+    return int(r + 8 if r < 0.9 * c2 else r)
+
+
+def block_table(phi: int) -> List[dict]:
+    """MBConv block list: efficientnet/utils.py:231-257 strings scaled by utils.py:62-82 and
+    expanded by efficientnet/model.py:144-160."""
+    wm, dm = _SCALING[_BACKBONE_OF_PHI[phi]]
+    out = []
+    for (r, k, s, e, i, o) in _STAGES:
+        ci, co = _round_width(i, wm), _round_width(o, wm)
+        for j in range(int(math.ceil(dm * r))):
+            out.append(dict(k=k, s=s if j == 0 else 1, e=e, cin=ci if j == 0 else co, cout=co,
+                            skip=j > 0))   # first block of a stage: stride is a list -> never adds (model.py:100)
+    return out
+
+
+def mbconv(sd, p: str, blk: dict, x: torch.Tensor) -> torch.Tensor:
+    """MBConvBlock.forward, efficientnet/model.py:69-104."""
+    inp = x
+    if blk["e"] != 1:
+        x = swish(bn(sd, p + "._bn0", conv_same(x, sd[p + "._expand_conv.conv.weight"])))
+    wdw = sd[p + "._depthwise_conv.conv.weight"]
+    x = swish(bn(sd, p + "._bn1", conv_same(x, wdw, stride=blk["s"], groups=wdw.shape[0])))
+    sq = F.adaptive_avg_pool2d(x, 1)
+    sq = swish(F.conv2d(sq, sd[p + "._se_reduce.conv.weight"], sd[p + "._se_reduce.conv.bias"]))
+    sq = F.conv2d(sq, sd[p + "._se_expand.conv.weight"], sd[p + "._se_expand.conv.bias"])
+    x = torch.sigmoid(sq) * x
+    x = bn(sd, p + "._bn2", conv_same(x, sd[p + "._project_conv.conv.weight"]))
+    if blk["skip"]:
+        x = x + inp
+    return x
+
+
+def backbone(sd, phi: int, x: torch.Tensor, trace: dict | None = None):
+    """EfficientNet wrapper forward, efficientdet/model.py:436-458, + the extra drop at
+    backbone.py:107: P3/P4/P5 are the last three taps."""
+    bb = "backbone_net.model"
+    x = swish(bn(sd, bb + "._bn0", conv_same(x, sd[bb + "._conv_stem.conv.weight"], stride=2)))
+    if trace is not None:
+        trace["stem"] = x
+    taps, last = [], None
+    blocks = block_table(phi)
+    for i, blk in enumerate(blocks):
+        x = mbconv(sd, f"{bb}._blocks.{i}", blk, x)
+        if trace is not None:
+            trace[f"block{i}"] = x
+        if blk["s"] == 2:
+            taps.append(last)
+        elif i == len(blocks) - 1:
+            taps.append(x)
+        last = x
+    return taps[-3:]
+
+
+def sepconv(sd, p: str, x: torch.Tensor, norm: bool) -> torch.Tensor:
+    """SeparableConvBlock.forward, efficientdet/model.py:42-52 (dw no bias, pw with bias)."""
+    wdw = sd[p + ".depthwise_conv.conv.weight"]
+    x = conv_same(x, wdw, groups=wdw.shape[0])
+    x = F.conv2d(x, sd[p + ".pointwise_conv.conv.weight"], sd[p + ".pointwise_conv.conv.bias"])
+    return bn(sd, p + ".bn", x) if norm else x
+
+
+def _lateral(sd, p: str, x):
+    return bn(sd, p + ".1", F.conv2d(x, sd[p + ".0.conv.weight"], sd[p + ".0.conv.bias"]))
+
+
+def _fw(sd, key: str, attention: bool, n: int):
+    """relu(w)/(sum(relu(w))+1e-4), efficientdet/model.py:212-213; plain sum for phi>=6 (:268-341)."""
+    if not attention:
+        return [1.0] * n
+    w = F.relu(sd[key])
+    w = w / (w.sum() + FUSION_EPS)
+    return [w[i] for i in range(n)]
+
+
+def bifpn_cell(sd, p: str, feats, first: bool, attention: bool):
+    """BiFPN._forward_fast_attention, efficientdet/model.py:194-266."""
+    up = lambda t: F.interpolate(t, scale_factor=2, mode="nearest")
+    if first:
+        p3, p4, p5 = feats
+        p6_in = maxpool_same(_lateral(sd, p + ".p5_to_p6", p5))
+        p7_in = maxpool_same(p6_in)
+        p3_in = _lateral(sd, p + ".p3_down_channel", p3)
+        p4_in = _lateral(sd, p + ".p4_down_channel", p4)
+        p5_in = _lateral(sd, p + ".p5_down_channel", p5)
+    else:
+        p3_in, p4_in, p5_in, p6_in, p7_in = feats
+    w = _fw(sd, p + ".p6_w1", attention, 2)
+    p6_up = sepconv(sd, p + ".conv6_up", swish(w[0] * p6_in + w[1] * up(p7_in)), True)
+    w = _fw(sd, p + ".p5_w1", attention, 2)
+    p5_up = sepconv(sd, p + ".conv5_up", swish(w[0] * p5_in + w[1] * up(p6_up)), True)
+    w = _fw(sd, p + ".p4_w1", attention, 2)
+    p4_up = sepconv(sd, p + ".conv4_up", swish(w[0] * p4_in + w[1] * up(p5_up)), True)
+    w = _fw(sd, p + ".p3_w1", attention, 2)
+    p3_out = sepconv(sd, p + ".conv3_up", swish(w[0] * p3_in + w[1] * up(p4_up)), True)
+    if first:   # a SECOND lateral projection feeds the bottom-up path (model.py:236-237)
+        p4_in = _lateral(sd, p + ".p4_down_channel_2", p4)
+        p5_in = _lateral(sd, p + ".p5_down_channel_2", p5)
+    w = _fw(sd, p + ".p4_w2", attention, 3)
+    p4_out = sepconv(sd, p + ".conv4_down", swish(w[0] * p4_in + w[1] * p4_up + w[2] * maxpool_same(p3_out)), True)
+    w = _fw(sd, p + ".p5_w2", attention, 3)
+    p5_out = sepconv(sd, p + ".conv5_down", swish(w[0] * p5_in + w[1] * p5_up + w[2] * maxpool_same(p4_out)), True)
+    w = _fw(sd, p + ".p6_w2", attention, 3)
+    p6_out = sepconv(sd, p + ".conv6_down", swish(w[0] * p6_in + w[1] * p6_up + w[2] * maxpool_same(p5_out)), True)
+    w = _fw(sd, p + ".p7_w2", attention, 2)
+    p7_out = sepconv(sd, p + ".conv7_down", swish(w[0] * p7_in + w[1] * maxpool_same(p6_out)), True)
+    return p3_out, p4_out, p5_out, p6_out, p7_out
+
+
+def head(sd, name: str, depth: int, feats, headers: List[Tuple[str, int]], sigmoid=False) -> torch.Tensor:
+    """Regressor/Classifier.forward efficientdet/model.py:361-417 and RotationNet/TranslationNet/
+    HandNet.forward hmdegopose/model.py:55-90,127-156,191-228 with num_iteration_steps == 0:
+    shared conv_list, per-level bn_list, header(s); NHWC flatten -> [B, HW*9, K]; levels concatenated;
+    two headers (translation xy|z) are concatenated per anchor (model.py:214-220)."""
+    outs = []
+    for lvl, f in enumerate(feats):
+        for i in range(depth):
+            f = swish(bn(sd, f"{name}.bn_list.{lvl}.{i}", sepconv(sd, f"{name}.conv_list.{i}", f, False)))
+        parts = []
+        for hname, k in headers:
+            y = sepconv(sd, f"{name}.{hname}", f, False).permute(0, 2, 3, 1).contiguous()
+            parts.append(y.view(y.shape[0], -1, k))
+        outs.append(parts[0] if len(parts) == 1 else torch.cat(parts, dim=2))
+    y = torch.cat(outs, dim=1)
+    return y.sigmoid() if sigmoid else y
+
+
+@torch.no_grad()
+def forward(sd: Mapping[str, torch.Tensor], x: torch.Tensor, phi: int, trace: Dict[str, torch.Tensor] | None = None):
+    """HMDEgoPose.forward, backbone.py:104-125.  x: fp32 [B,3,S,S] (any strides).
+    Returns (features(5), regression[B,N,4], classification[B,N,1] (post-sigmoid),
+    rotation[B,N,3], translation_raw[B,N,3], hand[B,N,63])."""
+    attention = phi < 6
+    feats = backbone(sd, phi, x.float(), trace)
+    if trace is not None:
+        trace["p3"], trace["p4"], trace["p5"] = feats
+    for r in range(_FPN_REPEATS[phi]):
+        feats = bifpn_cell(sd, f"bifpn.{r}", feats, first=(r == 0), attention=attention)
+        if trace is not None:
+            for l, f in enumerate(feats):
+                trace[f"bifpn{r}_p{l + 3}"] = f
+    d = _HEAD_DEPTH[phi]
+    A = NUM_ANCHORS
+    regression = head(sd, "regressor", d, feats, [("header", 4)])
+    classification = head(sd, "classifier", d, feats, [("header", 1)], sigmoid=True)
+    rotation = head(sd, "rotation_net", d, feats, [("initial_rotation", 3)])
+    translation = head(sd, "translation_net", d, feats, [("initial_translation_xy", 2), ("initial_translation_z", 1)])
+    hand = head(sd, "hand_net", d, feats, [("initial_hand_coords", 63)])
+    return feats, regression, classification, rotation, translation, hand

@@ -1,0 +1,64 @@
+"""CPU: pin the oracle (oracle/) to the golden vectors captured from the real reference
+(tests/golden/make_golden.py).  Tolerances: 1e-5 abs + 1e-5 rel for the fp32 network
+(the reference and the restatement run the same ATen CPU kernels; differences are
+summation-order only), bit-exact for anchors."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import decode_ref as D
+from oracle import efficientpose_ref as R
+from hmd_ego_pose_amd.weights import seeded_state_dict
+from tests._util import CAMS, CASES, check_digest, golden_case, golden_meta, seeded_input, strides_for
+
+
+@pytest.mark.parametrize("size", [256, 512])
+def test_anchors_bit_exact(size, golden_dir):
+    meta = golden_meta()
+    a, t = D.anchors_for_size(size)
+    assert a.dtype == np.float32 and t.dtype == np.float32
+    assert hashlib.sha256(a.tobytes()).hexdigest() == meta[f"anchors_{size}_sha256"]
+    assert hashlib.sha256(t.tobytes()).hexdigest() == meta[f"translation_anchors_{size}_sha256"]
+    assert hashlib.sha256(t.tobytes()).hexdigest() == meta[f"fixture_translation_anchors_{size}_sha256"]
+    fx = np.load(f"{golden_dir}/anchors.npz")
+    sl = lambda v: np.concatenate([v[::53], v[-9:]])
+    assert np.array_equal(sl(t), fx[f"translation_anchors_{size}"])
+    assert np.array_equal(sl(a), fx[f"gen_anchors_{size}"])
+    if size == 256:
+        assert hashlib.sha256(a.tobytes()).hexdigest() == meta["fixture_anchors_256_sha256"]
+        assert np.array_equal(sl(a), fx["anchors_256"])
+        # known answers quoted in SURVEY.md section 8c
+        assert a[0].tolist() == [-12.0, -12.0, 20.0, 20.0]
+        assert a.shape == (12276, 4) and t.shape == (12276, 3)
+        assert abs(float(a.astype(np.float64).sum()) - 6285312.004671574) < 1e-6
+        assert float(t.astype(np.float64).sum()) == 3285504.0
+
+
+@pytest.mark.parametrize("tag", list(CASES))
+def test_network_forward_matches_reference(tag):
+    phi, size, batch, seed, kind = CASES[tag]
+    info, gold = golden_case(tag)
+    sd = seeded_state_dict(phi, seed)
+    x = torch.from_numpy(seeded_input((batch, 3, size, size), seed, kind))
+    trace = {}
+    feats, reg, cls, rot, trn, hand = R.forward(sd, x, phi, trace)
+    named = {"regression": reg, "classification": cls, "rotation": rot, "translation_raw": trn, "hand": hand}
+    for l, f in enumerate(feats):
+        named[f"feat{l + 3}"] = f.permute(0, 2, 3, 1)
+    for k, v in trace.items():
+        if f"trace_{k}" in info:
+            named[f"trace_{k}"] = v.permute(0, 2, 3, 1)
+    assert len(named) >= 10 + len([k for k in info if k.startswith("trace_")])
+    for k, v in named.items():
+        check_digest(k, v.numpy(), info[k], gold[k], strides_for(size, k), atol=1e-5, rtol=1e-5)
+    # decode against the reference's own format_bboxes / format_translation
+    anchors, t_anchors = D.anchors_for_size(size)
+    st = strides_for(size, "boxes")
+    for ci, cam in enumerate(CAMS):
+        boxes = D.decode_boxes(anchors, reg.numpy(), size)
+        trans = D.decode_translation(t_anchors, trn.numpy(), np.repeat(cam[None], batch, 0))
+        check_digest(f"boxes_cam{ci}", boxes, info[f"boxes_cam{ci}"], gold[f"boxes_cam{ci}"], st, atol=1e-4, rtol=1e-5)
+        check_digest(f"translation_cam{ci}", trans, info[f"translation_cam{ci}"], gold[f"translation_cam{ci}"], st,
+                     atol=1e-3, rtol=1e-5)
