@@ -1,0 +1,408 @@
+// hep_api.cpp - the C ABI of libhep.so (include/hep.h) and the forward executor:
+// eager stem launch (it reads the caller's input pointer) + one captured hipGraph for
+// everything behind it, replayed on the caller's stream.
+#include <stdio.h>
+#include <string.h>
+
+#include <fstream>
+#include <memory>
+
+#include "hep.h"
+#include "hep_host.h"
+
+using namespace hep;
+
+struct hep_handle { Session s; };
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+#define HIPRET(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(HEP_ERR_DEVICE, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+
+static const int kOutK[5] = {4, 1, 3, 3, 63};
+
+namespace hep {
+
+Session::~Session() {
+  for (auto& g : graphs) hipGraphExecDestroy(g.second);
+  for (Op& o : ops) if (o.kind == OP_SEP && o.sep.segs) hipFree((void*)o.sep.segs);
+  hipFree(d_weights); hipFree(d_arena);
+  for (int i = 0; i < 5; i++) { hipFree(d_out[i]); hipFree(d_feat_nchw[i]); }
+  hipFree(d_in); hipFree(d_anchors); hipFree(d_tanchors); hipFree(d_boxes); hipFree(d_trans); hipFree(d_cam);
+  hipFree(d_keys); hipFree(d_det);
+  if (stream) hipStreamDestroy(stream);
+}
+
+void launch_op(const Session& s, const Op& op, int batch, hipStream_t st, const float* in, const int64_t* strides) {
+  switch (op.kind) {
+    case OP_STEM: {
+      StemArgs a = op.stem; a.B = batch; a.in = in;
+      a.sn = strides[0]; a.sc = strides[1]; a.sh = strides[2]; a.sw = strides[3];
+      launch_stem(a, st); break;
+    }
+    case OP_PW: { PwArgs a = op.pw; a.M = batch * a.HW; launch_pw(a, st); break; }
+    case OP_DW: { DwArgs a = op.dw; a.B = batch; launch_dw(a, st); break; }
+    case OP_SE: { SeArgs a = op.se; a.B = batch; launch_se(a, st); break; }
+    case OP_POOL: { PoolArgs a = op.pool; a.B = batch; launch_pool(a, st); break; }
+    case OP_SEP: { SepArgs a = op.sep; a.B = batch; launch_sep(a, st); break; }
+  }
+}
+
+// forward = ops[0] (stem, eager: its input pointer belongs to the caller) + graph(ops[1..])
+int run_forward(Session* s, const float* in_dev, const int64_t* strides, int batch, hipStream_t st, std::string* err) {
+  const int64_t S = s->size;
+  const int64_t contiguous[4] = {3 * S * S, S * S, S, 1};
+  if (!strides) strides = contiguous;
+  launch_op(*s, s->ops[0], batch, st, in_dev, strides);
+  if (s->flags & HEP_FLAG_NO_GRAPH) {
+    for (size_t i = 1; i < s->ops.size(); i++) launch_op(*s, s->ops[i], batch, st, nullptr, nullptr);
+  } else {
+    auto it = s->graphs.find(batch);
+    if (it == s->graphs.end()) {
+      hipGraph_t g; hipGraphExec_t ge;
+      hipError_t e = hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal);
+      if (e != hipSuccess) { *err = std::string("hipStreamBeginCapture: ") + hipGetErrorString(e); return HEP_ERR_DEVICE; }
+      for (size_t i = 1; i < s->ops.size(); i++) launch_op(*s, s->ops[i], batch, s->stream, nullptr, nullptr);
+      e = hipStreamEndCapture(s->stream, &g);
+      if (e != hipSuccess) { *err = std::string("hipStreamEndCapture: ") + hipGetErrorString(e); return HEP_ERR_DEVICE; }
+      e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+      hipGraphDestroy(g);
+      if (e != hipSuccess) { *err = std::string("hipGraphInstantiate: ") + hipGetErrorString(e); return HEP_ERR_DEVICE; }
+      it = s->graphs.emplace(batch, ge).first;
+    }
+    hipError_t e = hipGraphLaunch(it->second, st);
+    if (e != hipSuccess) { *err = std::string("hipGraphLaunch: ") + hipGetErrorString(e); return HEP_ERR_DEVICE; }
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { *err = std::string("kernel launch: ") + hipGetErrorString(e); return HEP_ERR_DEVICE; }
+  s->last_batch = batch;
+  return 0;
+}
+
+}  // namespace hep
+
+extern "C" {
+
+int hep_abi_version(void) { return HEP_ABI_VERSION; }
+const char* hep_last_error(void) { return g_err.c_str(); }
+
+int hep_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int hep_create_from_memory(const void* pack, size_t pack_bytes, int phi, int size, int max_batch, int dtype, int device,
+                           unsigned flags, hep_handle** out) {
+  if (!out) return fail(HEP_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  if (!pack || pack_bytes < 12) return fail(HEP_ERR_PACK, "weight pack: empty");
+  if (dtype != HEP_F32 && dtype != HEP_BF16) return fail(HEP_ERR_INVALID, "dtype must be HEP_F32 or HEP_BF16");
+  if (max_batch < 1 || max_batch > 4096) return fail(HEP_ERR_INVALID, "max_batch out of range (1..4096)");
+  if (size < 128 || size > 2048 || size % 128 != 0)
+    return fail(HEP_ERR_UNSUPPORTED, "size must be a multiple of 128 in [128, 2048] (P7 has stride 128)");
+  std::unique_ptr<hep_handle> h(new hep_handle);
+  Session& s = h->s;
+  if (!make_arch(phi, &s.arch)) return fail(HEP_ERR_UNSUPPORTED, "phi must be in 0..7 (phi 8 needs a P8 level)");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+    return fail(HEP_ERR_DEVICE, "no HIP device visible: libhep has no CPU fallback");
+  if (device < 0 || device >= ndev) return fail(HEP_ERR_INVALID, "device index out of range");
+  hipDeviceProp_t prop;
+  HIPRET(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(HEP_ERR_DEVICE, std::string("device is ") + prop.gcnArchName + ", libhep is built for gfx950 (MI355X) only");
+  s.size = size; s.max_batch = max_batch; s.dtype = dtype; s.device = device; s.flags = flags;
+  Pack pk; std::string err;
+  if (!pk.parse(pack, pack_bytes, &err)) return fail(HEP_ERR_PACK, err);
+  int rc = build_session(&s, pk, &err);
+  if (rc != 0) return fail(rc, err);
+  *out = h.release();
+  return 0;
+}
+
+int hep_create(const char* pack_path, int phi, int size, int max_batch, int dtype, int device, unsigned flags, hep_handle** out) {
+  if (out) *out = nullptr;
+  if (!pack_path) return fail(HEP_ERR_INVALID, "pack_path is NULL");
+  std::ifstream f(pack_path, std::ios::binary | std::ios::ate);
+  if (!f) return fail(HEP_ERR_PACK, std::string("cannot open weight pack '") + pack_path + "'");
+  const std::streamsize n = f.tellg();
+  f.seekg(0);
+  std::vector<char> buf((size_t)n);
+  if (!f.read(buf.data(), n)) return fail(HEP_ERR_PACK, "cannot read weight pack");
+  return hep_create_from_memory(buf.data(), buf.size(), phi, size, max_batch, dtype, device, flags, out);
+}
+
+void hep_destroy(hep_handle* h) {
+  if (!h) return;
+  hipSetDevice(h->s.device);
+  hipDeviceSynchronize();
+  delete h;
+}
+
+int hep_num_anchors(const hep_handle* h) { return h ? h->s.num_anchors : fail(HEP_ERR_INVALID, "handle is NULL"); }
+
+int hep_output_shape(const hep_handle* h, int index, int batch, int64_t dims[4], int* ndim) {
+  if (!h || !dims || index < 0 || index >= HEP_NUM_OUTPUTS) return fail(HEP_ERR_INVALID, "bad argument");
+  const Session& s = h->s;
+  if (index < 5) { dims[0] = batch; dims[1] = s.arch.fpn_w; dims[2] = s.levels[index]; dims[3] = s.levels[index]; if (ndim) *ndim = 4; }
+  else { dims[0] = batch; dims[1] = s.num_anchors; dims[2] = kOutK[index - 5]; dims[3] = 1; if (ndim) *ndim = 3; }
+  return 0;
+}
+
+static int check_run(hep_handle* h, const void* input, int batch) {
+  if (!h) return fail(HEP_ERR_INVALID, "handle is NULL");
+  if (!input) return fail(HEP_ERR_INVALID, "input is NULL");
+  if (batch < 1 || batch > h->s.max_batch) return fail(HEP_ERR_UNSUPPORTED, "batch outside 1..max_batch given to hep_create");
+  return 0;
+}
+
+static int export_feats(Session& s, int batch, float* const feats[5], bool device_dst, hipStream_t st) {
+  if (!feats) return 0;
+  for (int l = 0; l < 5; l++) {
+    if (!feats[l]) continue;
+    const TensorDesc& t = s.tensors[s.feat_ids[l]];
+    const size_t n = (size_t)batch * t.H * t.W * t.C;
+    float* dst = feats[l];
+    if (!device_dst) {
+      if (!s.d_feat_nchw[l]) HIPRET(hipMalloc((void**)&s.d_feat_nchw[l], (size_t)s.max_batch * t.H * t.W * t.C * 4));
+      dst = s.d_feat_nchw[l];
+    }
+    ExportArgs a; a.in = s.tptr(s.feat_ids[l]); a.out = dst; a.B = batch; a.H = t.H; a.W = t.W; a.C = t.C; a.bf16 = s.dtype;
+    launch_export(a, st);
+    if (!device_dst) HIPRET(hipMemcpyAsync(feats[l], dst, n * 4, hipMemcpyDeviceToHost, st));
+  }
+  return 0;
+}
+
+int hep_run_device(hep_handle* h, const float* input, const int64_t in_strides[4], int batch, float* const outs[5],
+                   float* const feats[5], void* stream) {
+  if (int rc = check_run(h, input, batch)) return rc;
+  Session& s = h->s;
+  std::lock_guard<std::mutex> lk(s.mu);
+  HIPRET(hipSetDevice(s.device));
+  hipStream_t st = (hipStream_t)stream;
+  std::string err;
+  if (int rc = run_forward(&s, input, in_strides, batch, st, &err)) return fail(rc, err);
+  if (outs)
+    for (int i = 0; i < 5; i++)
+      if (outs[i] && outs[i] != s.d_out[i])
+        HIPRET(hipMemcpyAsync(outs[i], s.d_out[i], (size_t)batch * s.num_anchors * kOutK[i] * 4, hipMemcpyDeviceToDevice, st));
+  return export_feats(s, batch, feats, true, st);
+}
+
+int hep_run(hep_handle* h, const float* input_nchw, int batch, float* const feats[5], float* regression, float* classification,
+            float* rotation, float* translation_raw, float* hand) {
+  if (int rc = check_run(h, input_nchw, batch)) return rc;
+  Session& s = h->s;
+  std::lock_guard<std::mutex> lk(s.mu);
+  HIPRET(hipSetDevice(s.device));
+  const size_t in_floats = (size_t)3 * s.size * s.size;
+  if (!s.d_in) HIPRET(hipMalloc((void**)&s.d_in, in_floats * s.max_batch * 4));
+  HIPRET(hipMemcpyAsync(s.d_in, input_nchw, in_floats * batch * 4, hipMemcpyHostToDevice, s.stream));
+  std::string err;
+  if (int rc = run_forward(&s, s.d_in, nullptr, batch, s.stream, &err)) return fail(rc, err);
+  float* outs[5] = {regression, classification, rotation, translation_raw, hand};
+  for (int i = 0; i < 5; i++)
+    if (outs[i]) HIPRET(hipMemcpyAsync(outs[i], s.d_out[i], (size_t)batch * s.num_anchors * kOutK[i] * 4, hipMemcpyDeviceToHost, s.stream));
+  if (int rc = export_feats(s, batch, feats, false, s.stream)) return rc;
+  HIPRET(hipStreamSynchronize(s.stream));
+  return 0;
+}
+
+int hep_anchors(int size, float* anchors, float* translation_anchors) {
+  if (size < 128 || size % 128 != 0) return fail(HEP_ERR_UNSUPPORTED, "size must be a positive multiple of 128");
+  std::vector<float> a, t;
+  const int n = host_anchors(size, anchors ? &a : nullptr, translation_anchors ? &t : nullptr);
+  if (anchors) memcpy(anchors, a.data(), a.size() * 4);
+  if (translation_anchors) memcpy(translation_anchors, t.data(), t.size() * 4);
+  return n;
+}
+
+int hep_decode_device(hep_handle* h, const float* regression, const float* translation_raw, const float* camera, int batch,
+                      float* boxes, float* translation, void* stream) {
+  if (!h || !camera || !boxes || !translation) return fail(HEP_ERR_INVALID, "bad argument");
+  Session& s = h->s;
+  if (batch < 1 || batch > s.max_batch) return fail(HEP_ERR_UNSUPPORTED, "batch outside 1..max_batch");
+  std::lock_guard<std::mutex> lk(s.mu);
+  HIPRET(hipSetDevice(s.device));
+  DecodeArgs a;
+  a.regression = regression ? regression : s.d_out[0];         // NULL = the handle's own last outputs
+  a.translation_raw = translation_raw ? translation_raw : s.d_out[3];
+  a.camera = camera; a.anchors = s.d_anchors; a.t_anchors = s.d_tanchors; a.boxes = boxes; a.translation = translation;
+  a.B = batch; a.N = s.num_anchors; a.clip_max = (float)(s.size - 1);
+  launch_decode(a, (hipStream_t)stream);
+  HIPRET(hipGetLastError());
+  return 0;
+}
+
+static int ensure_post(Session& s) {
+  const size_t n = (size_t)s.max_batch * s.num_anchors;
+  if (!s.d_boxes) HIPRET(hipMalloc((void**)&s.d_boxes, n * 4 * 4));
+  if (!s.d_trans) HIPRET(hipMalloc((void**)&s.d_trans, n * 3 * 4));
+  if (!s.d_cam) HIPRET(hipMalloc((void**)&s.d_cam, (size_t)s.max_batch * 6 * 4));
+  if (!s.d_keys) {
+    s.npow2 = 1; while (s.npow2 < s.num_anchors) s.npow2 <<= 1;
+    HIPRET(hipMalloc((void**)&s.d_keys, (size_t)s.max_batch * s.npow2 * 8));
+  }
+  return 0;
+}
+
+int hep_decode(hep_handle* h, const float* regression, const float* translation_raw, const float* camera, int batch,
+               float* boxes, float* translation) {
+  if (!h || !camera || !boxes || !translation) return fail(HEP_ERR_INVALID, "bad argument");
+  Session& s = h->s;
+  if (batch < 1 || batch > s.max_batch) return fail(HEP_ERR_UNSUPPORTED, "batch outside 1..max_batch");
+  {
+    std::lock_guard<std::mutex> lk(s.mu);
+    HIPRET(hipSetDevice(s.device));
+    if (int rc = ensure_post(s)) return rc;
+    const size_t n = (size_t)batch * s.num_anchors;
+    // host inputs are staged into the handle's own output buffers (they hold the same tensors)
+    if (regression) HIPRET(hipMemcpyAsync(s.d_out[0], regression, n * 16, hipMemcpyHostToDevice, s.stream));
+    if (translation_raw) HIPRET(hipMemcpyAsync(s.d_out[3], translation_raw, n * 12, hipMemcpyHostToDevice, s.stream));
+    HIPRET(hipMemcpyAsync(s.d_cam, camera, (size_t)batch * 24, hipMemcpyHostToDevice, s.stream));
+  }
+  if (int rc = hep_decode_device(h, nullptr, nullptr, s.d_cam, batch, s.d_boxes, s.d_trans, s.stream)) return rc;
+  const size_t n = (size_t)batch * s.num_anchors;
+  HIPRET(hipMemcpyAsync(boxes, s.d_boxes, n * 16, hipMemcpyDeviceToHost, s.stream));
+  HIPRET(hipMemcpyAsync(translation, s.d_trans, n * 12, hipMemcpyDeviceToHost, s.stream));
+  HIPRET(hipStreamSynchronize(s.stream));
+  return 0;
+}
+
+int hep_filter_device(hep_handle* h, const float* boxes, const float* classification, const float* rotation,
+                      const float* translation, const float* hand, int batch, float score_threshold, float nms_threshold,
+                      int max_detections, float* det_boxes, float* det_scores, int32_t* det_labels, float* det_rotation,
+                      float* det_translation, float* det_hand, int32_t* det_index, int32_t* det_count, void* stream) {
+  if (!h || !boxes || !det_count) return fail(HEP_ERR_INVALID, "bad argument");
+  Session& s = h->s;
+  if (batch < 1 || batch > s.max_batch) return fail(HEP_ERR_UNSUPPORTED, "batch outside 1..max_batch");
+  if (max_detections < 1 || max_detections > 256) return fail(HEP_ERR_UNSUPPORTED, "max_detections must be in 1..256");
+  std::lock_guard<std::mutex> lk(s.mu);
+  HIPRET(hipSetDevice(s.device));
+  if (int rc = ensure_post(s)) return rc;
+  FilterArgs a;
+  a.boxes = boxes; a.scores = classification ? classification : s.d_out[1];
+  a.rotation = rotation ? rotation : s.d_out[2]; a.translation = translation ? translation : s.d_trans;
+  a.hand = hand ? hand : s.d_out[4];
+  a.B = batch; a.N = s.num_anchors; a.max_det = max_detections; a.score_thr = score_threshold; a.nms_thr = nms_threshold;
+  a.keys = s.d_keys; a.npow2 = s.npow2;
+  a.det_boxes = det_boxes; a.det_scores = det_scores; a.det_labels = det_labels; a.det_rotation = det_rotation;
+  a.det_translation = det_translation; a.det_hand = det_hand; a.det_index = det_index; a.det_count = det_count;
+  launch_filter(a, (hipStream_t)stream);
+  HIPRET(hipGetLastError());
+  return 0;
+}
+
+int hep_filter(hep_handle* h, const float* boxes, const float* classification, const float* rotation, const float* translation,
+               const float* hand, int batch, float score_threshold, float nms_threshold, int max_detections, float* det_boxes,
+               float* det_scores, int32_t* det_labels, float* det_rotation, float* det_translation, float* det_hand,
+               int32_t* det_index, int32_t* det_count) {
+  if (!h || !boxes || !classification || !rotation || !translation || !hand || !det_count) return fail(HEP_ERR_INVALID, "bad argument");
+  Session& s = h->s;
+  if (batch < 1 || batch > s.max_batch) return fail(HEP_ERR_UNSUPPORTED, "batch outside 1..max_batch");
+  if (max_detections < 1 || max_detections > 256) return fail(HEP_ERR_UNSUPPORTED, "max_detections must be in 1..256");
+  const size_t n = (size_t)batch * s.num_anchors, M = (size_t)batch * max_detections;
+  float* d = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(s.mu);
+    HIPRET(hipSetDevice(s.device));
+    if (int rc = ensure_post(s)) return rc;
+    const size_t need = (size_t)s.max_batch * 256 * (4 + 1 + 1 + 3 + 3 + 63 + 1) + s.max_batch;
+    if (!s.d_det) { HIPRET(hipMalloc((void**)&s.d_det, need * 4)); s.det_floats = need; }
+    d = s.d_det;
+    HIPRET(hipMemcpyAsync(s.d_boxes, boxes, n * 16, hipMemcpyHostToDevice, s.stream));
+    HIPRET(hipMemcpyAsync(s.d_out[1], classification, n * 4, hipMemcpyHostToDevice, s.stream));
+    HIPRET(hipMemcpyAsync(s.d_out[2], rotation, n * 12, hipMemcpyHostToDevice, s.stream));
+    HIPRET(hipMemcpyAsync(s.d_trans, translation, n * 12, hipMemcpyHostToDevice, s.stream));
+    HIPRET(hipMemcpyAsync(s.d_out[4], hand, n * 63 * 4, hipMemcpyHostToDevice, s.stream));
+  }
+  float* b_ = d; float* sc_ = b_ + M * 4; int32_t* lb_ = (int32_t*)(sc_ + M); float* ro_ = (float*)(lb_ + M);
+  float* tr_ = ro_ + M * 3; float* hd_ = tr_ + M * 3; int32_t* ix_ = (int32_t*)(hd_ + M * 63); int32_t* ct_ = ix_ + M;
+  if (int rc = hep_filter_device(h, s.d_boxes, nullptr, nullptr, nullptr, nullptr, batch, score_threshold, nms_threshold,
+                                 max_detections, b_, sc_, lb_, ro_, tr_, hd_, ix_, ct_, s.stream)) return rc;
+  if (det_boxes) HIPRET(hipMemcpyAsync(det_boxes, b_, M * 16, hipMemcpyDeviceToHost, s.stream));
+  if (det_scores) HIPRET(hipMemcpyAsync(det_scores, sc_, M * 4, hipMemcpyDeviceToHost, s.stream));
+  if (det_labels) HIPRET(hipMemcpyAsync(det_labels, lb_, M * 4, hipMemcpyDeviceToHost, s.stream));
+  if (det_rotation) HIPRET(hipMemcpyAsync(det_rotation, ro_, M * 12, hipMemcpyDeviceToHost, s.stream));
+  if (det_translation) HIPRET(hipMemcpyAsync(det_translation, tr_, M * 12, hipMemcpyDeviceToHost, s.stream));
+  if (det_hand) HIPRET(hipMemcpyAsync(det_hand, hd_, M * 63 * 4, hipMemcpyDeviceToHost, s.stream));
+  if (det_index) HIPRET(hipMemcpyAsync(det_index, ix_, M * 4, hipMemcpyDeviceToHost, s.stream));
+  HIPRET(hipMemcpyAsync(det_count, ct_, (size_t)batch * 4, hipMemcpyDeviceToHost, s.stream));
+  HIPRET(hipStreamSynchronize(s.stream));
+  return 0;
+}
+
+// ---- introspection ----
+int hep_debug_tensor_count(const hep_handle* h) { return h ? (int)h->s.tensors.size() : 0; }
+int hep_debug_tensor_info(const hep_handle* h, int i, const char** name, int64_t dims[4]) {
+  if (!h || i < 0 || i >= (int)h->s.tensors.size()) return fail(HEP_ERR_INVALID, "bad tensor index");
+  const TensorDesc& t = h->s.tensors[i];
+  if (name) *name = t.name.c_str();
+  if (dims) { dims[0] = h->s.max_batch; dims[1] = t.H; dims[2] = t.W; dims[3] = t.C; }
+  return 0;
+}
+int hep_debug_tensor(hep_handle* h, const char* name, int batch, float* out, size_t capacity) {
+  if (!h || !name || !out) return fail(HEP_ERR_INVALID, "bad argument");
+  Session& s = h->s;
+  auto it = s.tensor_by_name.find(name);
+  if (it == s.tensor_by_name.end()) return fail(HEP_ERR_INVALID, std::string("no stage tensor named '") + name + "'");
+  const TensorDesc& t = s.tensors[it->second];
+  const size_t n = (size_t)batch * t.H * t.W * t.C;
+  if (n > capacity) return fail(HEP_ERR_INVALID, "output buffer too small");
+  std::lock_guard<std::mutex> lk(s.mu);
+  HIPRET(hipSetDevice(s.device));
+  HIPRET(hipDeviceSynchronize());
+  if (t.f32 || s.dtype == HEP_F32) { HIPRET(hipMemcpy(out, s.tptr(it->second), n * 4, hipMemcpyDeviceToHost)); }
+  else {
+    std::vector<uint16_t> tmp(n);
+    HIPRET(hipMemcpy(tmp.data(), s.tptr(it->second), n * 2, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; i++) { uint32_t u = (uint32_t)tmp[i] << 16; memcpy(&out[i], &u, 4); }
+  }
+  return 0;
+}
+
+int hep_kernel_count(const hep_handle* h, int) { return h ? (int)h->s.ops.size() : 0; }
+int hep_kernel_info(const hep_handle* h, int batch, int i, const char** name, double* bytes, double* flops) {
+  if (!h || i < 0 || i >= (int)h->s.ops.size()) return fail(HEP_ERR_INVALID, "bad kernel index");
+  const Op& o = h->s.ops[i];
+  if (name) *name = o.name.c_str();
+  if (bytes) *bytes = o.act_bytes_per_image * batch + o.weight_bytes;
+  if (flops) *flops = o.flops_per_image * batch;
+  return 0;
+}
+
+int hep_profile(hep_handle* h, int batch, int iters, float* total_ms_per_iter, float* per_kernel_ms) {
+  if (!h || iters < 1) return fail(HEP_ERR_INVALID, "bad argument");
+  Session& s = h->s;
+  if (batch < 1 || batch > s.max_batch) return fail(HEP_ERR_UNSUPPORTED, "batch outside 1..max_batch");
+  std::lock_guard<std::mutex> lk(s.mu);
+  HIPRET(hipSetDevice(s.device));
+  const size_t in_floats = (size_t)3 * s.size * s.size;
+  if (!s.d_in) { HIPRET(hipMalloc((void**)&s.d_in, in_floats * s.max_batch * 4)); HIPRET(hipMemset(s.d_in, 0, in_floats * s.max_batch * 4)); }
+  hipEvent_t e0, e1; HIPRET(hipEventCreate(&e0)); HIPRET(hipEventCreate(&e1));
+  std::string err;
+  const int64_t S = s.size; const int64_t st[4] = {3 * S * S, S * S, S, 1};
+  for (int w = 0; w < 3; w++) if (int rc = run_forward(&s, s.d_in, st, batch, s.stream, &err)) return fail(rc, err);
+  HIPRET(hipEventRecord(e0, s.stream));
+  for (int i = 0; i < iters; i++) if (int rc = run_forward(&s, s.d_in, st, batch, s.stream, &err)) return fail(rc, err);
+  HIPRET(hipEventRecord(e1, s.stream));
+  HIPRET(hipEventSynchronize(e1));
+  float ms = 0; HIPRET(hipEventElapsedTime(&ms, e0, e1));
+  if (total_ms_per_iter) *total_ms_per_iter = ms / iters;
+  if (per_kernel_ms) {
+    for (size_t k = 0; k < s.ops.size(); k++) {
+      for (int w = 0; w < 2; w++) launch_op(s, s.ops[k], batch, s.stream, s.d_in, st);
+      HIPRET(hipEventRecord(e0, s.stream));
+      for (int i = 0; i < iters; i++) launch_op(s, s.ops[k], batch, s.stream, s.d_in, st);
+      HIPRET(hipEventRecord(e1, s.stream));
+      HIPRET(hipEventSynchronize(e1));
+      HIPRET(hipEventElapsedTime(&ms, e0, e1));
+      per_kernel_ms[k] = ms / iters;
+    }
+  }
+  hipEventDestroy(e0); hipEventDestroy(e1);
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,82 @@
+// hep_dev.h - device-side helpers for the gfx950 kernels (wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t hi16) { return __uint_as_float(hi16 << 16); }
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  // plain casts lower to v_cvt_pk_bf16_f32 (RNE, NaN-preserving) on gfx950
+  bf16_t a = (bf16_t)lo, b = (bf16_t)hi;
+  return (uint32_t)__builtin_bit_cast(uint16_t, a) | ((uint32_t)__builtin_bit_cast(uint16_t, b) << 16);
+}
+
+__device__ __forceinline__ float swishf(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float apply_act(float x, int act) {
+  return act == 1 ? swishf(x) : (act == 2 ? sigmoidf(x) : x);
+}
+
+// 8 consecutive channels <-> 8 floats
+template <bool BF16> struct Vec8;
+template <> struct Vec8<true> {
+  typedef bf16_t elem;
+  static __device__ __forceinline__ void load(const void* base, int64_t idx, float v[8]) {
+    u32x4 r = *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(base) + idx);
+#pragma unroll
+    for (int i = 0; i < 4; i++) { v[2 * i] = __uint_as_float(r[i] << 16); v[2 * i + 1] = __uint_as_float(r[i] & 0xffff0000u); }
+  }
+  static __device__ __forceinline__ void store(void* base, int64_t idx, const float v[8]) {
+    u32x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; i++) r[i] = pack_bf16x2(v[2 * i], v[2 * i + 1]);
+    *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(base) + idx) = r;
+  }
+  static __device__ __forceinline__ void store4(void* base, int64_t idx, const float v[4]) {
+    u32x2 r; r[0] = pack_bf16x2(v[0], v[1]); r[1] = pack_bf16x2(v[2], v[3]);
+    *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(base) + idx) = r;
+  }
+  static __device__ __forceinline__ void load4(const void* base, int64_t idx, float v[4]) {
+    u32x2 r = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(base) + idx);
+    v[0] = __uint_as_float(r[0] << 16); v[1] = __uint_as_float(r[0] & 0xffff0000u);
+    v[2] = __uint_as_float(r[1] << 16); v[3] = __uint_as_float(r[1] & 0xffff0000u);
+  }
+};
+template <> struct Vec8<false> {
+  typedef float elem;
+  static __device__ __forceinline__ void load(const void* base, int64_t idx, float v[8]) {
+    const f32x4* p = reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(base) + idx);
+    f32x4 a = p[0], b = p[1];
+#pragma unroll
+    for (int i = 0; i < 4; i++) { v[i] = a[i]; v[4 + i] = b[i]; }
+  }
+  static __device__ __forceinline__ void store(void* base, int64_t idx, const float v[8]) {
+    f32x4* p = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + idx);
+    f32x4 a, b;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { a[i] = v[i]; b[i] = v[4 + i]; }
+    p[0] = a; p[1] = b;
+  }
+  static __device__ __forceinline__ void store4(void* base, int64_t idx, const float v[4]) {
+    f32x4 a; a[0] = v[0]; a[1] = v[1]; a[2] = v[2]; a[3] = v[3];
+    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + idx) = a;
+  }
+  static __device__ __forceinline__ void load4(const void* base, int64_t idx, float v[4]) {
+    f32x4 a = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(base) + idx);
+    v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
+  }
+};
+
+// XCD-aware block remap (guide T1): hardware deals consecutive block ids round-robin over the
+// 8 XCDs; give each XCD a contiguous range of logical ids so neighbours share an L2.  Bijective
+// for any grid size.
+__device__ __forceinline__ int xcd_remap(int orig, int nwg) {
+  int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+  int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + (orig >> 3);
+}

@@ -1,0 +1,88 @@
+// hep_host.h - host-side model description, weight pack and execution plan of libhep.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "hep_internal.h"
+
+namespace hep {
+
+// ---- architecture tables (mirror of hmd_ego_pose_amd/arch.py; reference backbone.py:22-43,
+//      efficientnet/utils.py:62-82,138-153,231-257, efficientnet/model.py:144-160) ----
+struct MBConv { int cin, cexp, k, stride, se, cout; bool expand, skip; };
+struct Arch {
+  int phi, stem;
+  std::vector<MBConv> blocks;
+  int taps[3], tap_channels[3];
+  int fpn_w, fpn_cells, head_depth;
+  bool attention;
+};
+bool make_arch(int phi, Arch* out);
+void same_pad(int n, int k, int s, int* before, int* after);
+
+// ---- HEPW weight pack (hmd_ego_pose_amd/weights.py) ----
+struct PackTensor { std::vector<int64_t> dims; const float* data; size_t count; };
+struct Pack {
+  std::vector<unsigned char> storage;
+  std::unordered_map<std::string, PackTensor> tensors;
+  bool parse(const void* blob, size_t n, std::string* err);
+  const PackTensor* get(const std::string& name, std::initializer_list<int64_t> dims, std::string* err) const;
+};
+
+// ---- plan ----
+struct TensorDesc {
+  std::string name;
+  int H, W, C; bool f32;            // NHWC; f32 forces fp32 storage (head outputs, SE buffers)
+  size_t bytes_per_image; size_t offset;
+  int first_op = -1, last_op = -1;
+  bool external = false;            // lives in its own allocation (outputs)
+  void* ext_ptr = nullptr;
+};
+
+enum OpKind { OP_STEM, OP_PW, OP_DW, OP_SE, OP_POOL, OP_SEP };
+struct Op {
+  OpKind kind; std::string name;
+  StemArgs stem; PwArgs pw; DwArgs dw; SeArgs se; PoolArgs pool; SepArgs sep;
+  std::vector<SepSeg> segs;         // host copy (device copy uploaded at build)
+  std::vector<int> reads, writes;   // tensor ids
+  double act_bytes_per_image = 0, flops_per_image = 0, weight_bytes = 0;
+};
+
+struct Session {
+  Arch arch; int size, max_batch, dtype, device; unsigned flags;
+  int levels[5]; int level_off[5]; int num_anchors;
+  std::vector<TensorDesc> tensors;
+  std::vector<Op> ops;
+  std::unordered_map<std::string, int> tensor_by_name;
+  int feat_ids[5];
+  // device memory
+  unsigned char* d_weights = nullptr; size_t weights_bytes = 0;
+  unsigned char* d_arena = nullptr; size_t arena_bytes = 0;
+  float* d_out[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // regression, classification, rotation, translation_raw, hand
+  float* d_in = nullptr;            // staging for host-buffer runs
+  float* d_feat_nchw[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  float* d_anchors = nullptr; float* d_tanchors = nullptr;
+  float* d_boxes = nullptr; float* d_trans = nullptr; float* d_cam = nullptr;
+  uint64_t* d_keys = nullptr; int npow2 = 0;
+  float* d_det = nullptr; size_t det_floats = 0;   // staging for host-buffer filter
+  hipStream_t stream = nullptr;     // handle's own stream (host API, capture, profiling)
+  std::map<int, hipGraphExec_t> graphs;   // per batch size
+  std::mutex mu;
+  int last_batch = 0;
+
+  ~Session();
+  void* tptr(int id) const { const TensorDesc& t = tensors[id]; return t.external ? t.ext_ptr : (void*)(d_arena + t.offset); }
+  size_t esize() const { return dtype == 1 ? 2 : 4; }
+};
+
+int build_session(Session* s, const Pack& pack, std::string* err);
+void launch_op(const Session& s, const Op& op, int batch, hipStream_t st, const float* in, const int64_t* strides);
+int run_forward(Session* s, const float* in_dev, const int64_t* strides, int batch, hipStream_t st, std::string* err);
+int host_anchors(int size, std::vector<float>* anchors, std::vector<float>* tanchors);
+
+}  // namespace hep

@@ -1,0 +1,100 @@
+// hep_internal.h - shared between the host plan builder and the gfx950 kernels.
+// Activations are NHWC ([B,H,W,C], C a multiple of 8) in `dtype` (fp32 or bf16);
+// biases, depthwise weights, SE weights and fusion weights are always fp32.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define HEP_MAX_SRC 3
+
+enum { ACT_NONE = 0, ACT_SWISH = 1, ACT_SIGMOID = 2 };
+enum { SRC_SAME = 1, SRC_UP = 2, SRC_DOWN = 3 };   // gather kinds of a BiFPN fusion input
+
+// ---- stem: conv3x3 s2 SAME, Cin=3 (+folded BN, swish); fp32 strided NCHW in -> NHWC out ----
+struct StemArgs {
+  const float* in; int64_t sn, sc, sh, sw;   // element strides of the caller's tensor
+  const float* w;      // [3][3][3][Cout] (ky,kx,ci,co), BN folded
+  const float* bias;   // [Cout]
+  void* out;           // [B,Ho,Wo,Cout]
+  int B, H, W, Ho, Wo, Cout, pad_t, pad_l, bf16;
+};
+
+// ---- pointwise conv as GEMM: out[M,N] = act((A[M,K] (*se)) . W[N,K]^T + bias) (+res) ----
+struct PwArgs {
+  const void* A; const void* W; const float* bias;
+  const float* se;     // [B,K] per-image input-channel scale (nullable)
+  const void* res;     // [M,N] residual (nullable)
+  void* out;
+  int M, K, N, tilesN; // tilesN = ceil(N/16); W holds tilesN*16 rows
+  int HW;              // rows per image (for se)
+  int act, bf16, MT, NT;
+};
+
+// ---- depthwise kxk conv + folded BN + swish (+ per-block channel sums for SE) ----
+struct DwArgs {
+  const void* in; const float* w /*[k*k][C]*/; const float* bias; void* out;
+  float* partial;      // [B][blocks_per_image][C] (nullable)
+  int B, H, W, C, Ho, Wo, k, s, pad_t, pad_l, act, bf16, TW, blocks_per_image;
+};
+
+// ---- squeeze-excite FCs: mean -> reduce(+swish) -> expand(+sigmoid) ----
+struct SeArgs {
+  const float* partial; int nblk; float inv_hw;
+  const float* wr /*[sq][C]*/; const float* br; const float* we /*[C][sq]*/; const float* be;
+  float* scale;        // [B][C]
+  int B, C, sq;
+};
+
+// ---- 3x3 s2 max-pool, TF-SAME with ZERO padding (utils_extra.py:72-86) ----
+struct PoolArgs { const void* in; void* out; int B, H, W, C, Ho, Wo, pad_t, pad_l, bf16; };
+
+// ---- fused separable conv segment: [fusion gather + swish] -> dw3x3 -> pw(+bias)(+act) ----
+struct SepSeg {
+  const void* src[HEP_MAX_SRC]; int kind[HEP_MAX_SRC]; float fw[HEP_MAX_SRC];
+  int sh[HEP_MAX_SRC], sw[HEP_MAX_SRC];    // source spatial size
+  int pool_pad[HEP_MAX_SRC];               // SAME pad-before of the 3/2 max-pool for SRC_DOWN
+  int nsrc, pre_act;                       // pre_act: swish after the weighted sum
+  int h, w, C;                             // dw input/output spatial size, channels
+  const float* wdw;                        // [9][C]
+  const void* wpw;                         // [tilesN*16][C] in dtype
+  const float* bias;                       // [tilesN*16]
+  int N, tilesN, act;
+  void* out; int out_f32;                  // fp32 head outputs, otherwise dtype
+  int64_t out_bstride, out_off, out_rowstride;   // elements: per image, level offset, per pixel
+  int col_kin, col_kout, col_off;          // column n -> (n/kin)*kout + n%kin + off
+  int tiles_x, tiles_y, tile_begin;        // 8x8 tiles; tile_begin = prefix over segments (incl. batch)
+};
+struct SepArgs { const SepSeg* segs; int nseg; int B; int total_tiles; int bf16; int C; size_t lds_bytes; };
+
+// ---- decode: boxes + translation from raw heads (loss.py:12-51) ----
+struct DecodeArgs {
+  const float* regression; const float* translation_raw; const float* camera;
+  const float* anchors; const float* t_anchors; float* boxes; float* translation;
+  int B, N; float clip_max;
+};
+
+// ---- feature export: NHWC dtype -> NCHW fp32 ----
+struct ExportArgs { const void* in; float* out; int B, H, W, C, bf16; };
+
+// ---- detection filter (layers.py:264-400) ----
+struct FilterArgs {
+  const float* boxes; const float* scores; const float* rotation; const float* translation; const float* hand;
+  int B, N, max_det; float score_thr, nms_thr;
+  uint64_t* keys;      // workspace [B][Npow2] sort keys
+  int npow2;
+  float* det_boxes; float* det_scores; int32_t* det_labels; float* det_rotation; float* det_translation;
+  float* det_hand; int32_t* det_index; int32_t* det_count;
+};
+
+void launch_stem(const StemArgs&, hipStream_t);
+void launch_pw(const PwArgs&, hipStream_t);
+void launch_dw(const DwArgs&, hipStream_t);
+void launch_se(const SeArgs&, hipStream_t);
+void launch_pool(const PoolArgs&, hipStream_t);
+void launch_sep(const SepArgs&, hipStream_t);
+void launch_decode(const DecodeArgs&, hipStream_t);
+void launch_export(const ExportArgs&, hipStream_t);
+void launch_filter(const FilterArgs&, hipStream_t);
+int dw_blocks_per_image(int Ho, int Wo, int C, int TW);
+size_t sep_lds_bytes(int C, int bf16);
+int sep_prepare(void);   // raises the dynamic-LDS limit of the sepconv kernels (call once per device)

@@ -1,0 +1,277 @@
+// k_dw.hip - the HBM-bound side of the EfficientNet backbone on gfx950: stem conv, depthwise
+// kxk conv (+BN+swish, + squeeze-excite partial sums), the SE fully-connected pair and the
+// zero-padded 3x3/2 max-pool.  NHWC activations, 8 channels (16 B in bf16) per lane so every
+// wave-level access is a run of full 16-byte vectors along C.
+#include "hep_dev.h"
+#include "hep_internal.h"
+
+// ------------------------------------------------------------------------------------------------
+// stem: conv3x3 stride 2, TF-SAME pad (0,1) on even sizes, 3 -> Cout, folded BN + swish.
+// Replaces `_conv_stem,_bn0,_swish` (reference efficientdet/model.py:437-439).  The caller's
+// fp32 tensor is read through its own strides, so the NHWC-memory view that
+// eval/common.py:397 produces needs no copy.
+// ------------------------------------------------------------------------------------------------
+template <bool BF16>
+__global__ __launch_bounds__(256) void stem_kernel(StemArgs a) {
+  const int CG = a.Cout >> 3;
+  const int64_t total = (int64_t)a.B * a.Ho * a.Wo * CG;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int cg = (int)(idx % CG);
+  int64_t p = idx / CG;
+  const int ox = (int)(p % a.Wo); p /= a.Wo;
+  const int oy = (int)(p % a.Ho);
+  const int b = (int)(p / a.Ho);
+  float acc[8];
+#pragma unroll
+  for (int c = 0; c < 8; c++) acc[c] = a.bias[cg * 8 + c];
+#pragma unroll
+  for (int ky = 0; ky < 3; ky++) {
+    const int iy = oy * 2 - a.pad_t + ky;
+    if (iy < 0 || iy >= a.H) continue;
+#pragma unroll
+    for (int kx = 0; kx < 3; kx++) {
+      const int ix = ox * 2 - a.pad_l + kx;
+      if (ix < 0 || ix >= a.W) continue;
+#pragma unroll
+      for (int ci = 0; ci < 3; ci++) {
+        const float x = a.in[b * a.sn + ci * a.sc + iy * a.sh + ix * a.sw];
+        const float* w = a.w + ((ky * 3 + kx) * 3 + ci) * a.Cout + cg * 8;
+#pragma unroll
+        for (int c = 0; c < 8; c++) acc[c] = fmaf(x, w[c], acc[c]);
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 8; c++) acc[c] = swishf(acc[c]);
+  Vec8<BF16>::store(a.out, idx * 8, acc);
+}
+
+void launch_stem(const StemArgs& a, hipStream_t s) {
+  const int64_t total = (int64_t)a.B * a.Ho * a.Wo * (a.Cout >> 3);
+  dim3 grid((unsigned)((total + 255) / 256));
+  if (a.bf16) hipLaunchKernelGGL(stem_kernel<true>, grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(stem_kernel<false>, grid, dim3(256), 0, s, a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// depthwise k x k, stride S, TF-SAME zero padding, folded BN + swish; replaces
+// `_depthwise_conv,_bn1,_swish` and the spatial half of `adaptive_avg_pool2d`
+// (reference efficientnet/model.py:83-89).
+// A lane owns 8 channels of a strip of TW output pixels along W: every input vector it loads
+// feeds up to K taps, and the K x K x 8 weights are loaded once per row of taps.
+// Squeeze-excite: each lane sums its post-swish outputs, the block reduces them through LDS in a
+// FIXED order and writes partial[b][block][c] - no atomics, so the result is bit-reproducible.
+// ------------------------------------------------------------------------------------------------
+template <bool BF16, int KS, int S, int TW>
+__global__ __launch_bounds__(256) void dw_kernel(DwArgs a) {
+  typedef Vec8<BF16> V;
+  __shared__ float red[256][9];
+  const int CG = a.C >> 3;
+  const int SW = (a.Wo + TW - 1) / TW;
+  const int nitems = a.Ho * SW * CG;
+  const int item = blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  const bool valid = item < nitems;
+  const int cg = valid ? item % CG : 0;
+  const int strip = valid ? item / CG : 0;
+  const int oy = strip / SW, ox0 = (strip % SW) * TW;
+  constexpr int WIN = (TW - 1) * S + KS;
+
+  float acc[TW][8];
+#pragma unroll
+  for (int p = 0; p < TW; p++)
+#pragma unroll
+    for (int c = 0; c < 8; c++) acc[p][c] = 0.f;
+  float sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+
+  if (valid) {
+    const int64_t img = (int64_t)b * a.H * a.W * a.C;
+#pragma unroll
+    for (int ky = 0; ky < KS; ky++) {
+      const int iy = oy * S - a.pad_t + ky;
+      if (iy < 0 || iy >= a.H) continue;
+      float w[KS][8];
+#pragma unroll
+      for (int kx = 0; kx < KS; kx++) {
+        const f32x4* wp = reinterpret_cast<const f32x4*>(a.w + (ky * KS + kx) * a.C + cg * 8);
+        f32x4 w0 = wp[0], w1 = wp[1];
+#pragma unroll
+        for (int c = 0; c < 4; c++) { w[kx][c] = w0[c]; w[kx][4 + c] = w1[c]; }
+      }
+#pragma unroll
+      for (int c0 = 0; c0 < WIN; c0++) {
+        const int ix = ox0 * S - a.pad_l + c0;
+        if (ix < 0 || ix >= a.W) continue;
+        float x[8];
+        V::load(a.in, img + ((int64_t)iy * a.W + ix) * a.C + cg * 8, x);
+#pragma unroll
+        for (int kx = 0; kx < KS; kx++) {
+          if ((c0 - kx) % S != 0 || c0 - kx < 0) continue;
+          constexpr int dummy = 0; (void)dummy;
+          const int p = (c0 - kx) / S;
+          if (p >= TW) continue;
+#pragma unroll
+          for (int c = 0; c < 8; c++) acc[p][c] = fmaf(x[c], w[kx][c], acc[p][c]);
+        }
+      }
+    }
+    float bias[8];
+    {
+      const f32x4* bp = reinterpret_cast<const f32x4*>(a.bias + cg * 8);
+      f32x4 b0 = bp[0], b1 = bp[1];
+#pragma unroll
+      for (int c = 0; c < 4; c++) { bias[c] = b0[c]; bias[4 + c] = b1[c]; }
+    }
+    const int64_t oimg = (int64_t)b * a.Ho * a.Wo * a.C;
+#pragma unroll
+    for (int p = 0; p < TW; p++) {
+      if (ox0 + p >= a.Wo) continue;
+      float v[8];
+#pragma unroll
+      for (int c = 0; c < 8; c++) { v[c] = apply_act(acc[p][c] + bias[c], a.act); sum[c] += v[c]; }
+      V::store(a.out, oimg + ((int64_t)oy * a.Wo + ox0 + p) * a.C + cg * 8, v);
+    }
+  }
+
+  if (a.partial) {   // deterministic per-block channel sums for the squeeze-excite mean
+#pragma unroll
+    for (int c = 0; c < 8; c++) red[threadIdx.x][c] = sum[c];
+    __syncthreads();
+    const int first_item = blockIdx.x * 256;
+    for (int o = threadIdx.x; o < CG * 8; o += 256) {
+      const int ocg = o >> 3, oc = o & 7;
+      int t = (ocg - first_item % CG + CG) % CG;    // first thread of this block owning channel group ocg
+      float s = 0.f;
+      for (; t < 256; t += CG) s += red[t][oc];
+      a.partial[((int64_t)b * a.blocks_per_image + blockIdx.x) * a.C + o] = s;
+    }
+  }
+}
+
+int dw_blocks_per_image(int Ho, int Wo, int C, int TW) {
+  const int SW = (Wo + TW - 1) / TW;
+  return (Ho * SW * (C >> 3) + 255) / 256;
+}
+
+template <bool BF16, int KS, int S>
+static void launch_dw_tw(const DwArgs& a, dim3 grid, hipStream_t s) {
+  switch (a.TW) {
+    case 1: hipLaunchKernelGGL((dw_kernel<BF16, KS, S, 1>), grid, dim3(256), 0, s, a); break;
+    case 2: hipLaunchKernelGGL((dw_kernel<BF16, KS, S, 2>), grid, dim3(256), 0, s, a); break;
+    default: hipLaunchKernelGGL((dw_kernel<BF16, KS, S, 4>), grid, dim3(256), 0, s, a); break;
+  }
+}
+template <bool BF16>
+static void launch_dw_t(const DwArgs& a, dim3 grid, hipStream_t s) {
+  if (a.k == 3 && a.s == 1) launch_dw_tw<BF16, 3, 1>(a, grid, s);
+  else if (a.k == 3 && a.s == 2) launch_dw_tw<BF16, 3, 2>(a, grid, s);
+  else if (a.k == 5 && a.s == 1) launch_dw_tw<BF16, 5, 1>(a, grid, s);
+  else launch_dw_tw<BF16, 5, 2>(a, grid, s);
+}
+void launch_dw(const DwArgs& a, hipStream_t s) {
+  dim3 grid(a.blocks_per_image, a.B);
+  if (a.bf16) launch_dw_t<true>(a, grid, s); else launch_dw_t<false>(a, grid, s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// squeeze-excite: mean over HW (from the per-block partial sums) -> reduce FC + swish ->
+// expand FC + sigmoid -> scale[b][c]; replaces `_se_reduce,_swish,_se_expand,sigmoid`
+// (reference efficientnet/model.py:90-93).  fp32 throughout; one block per image.  The scale is
+// applied by the project GEMM while it loads its A fragments.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void se_kernel(SeArgs a) {
+  extern __shared__ float sm[];          // mean[C] | hidden[sq]
+  float* mean = sm;
+  float* hid = sm + a.C;
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < a.C; c += 256) {
+    float s = 0.f;
+    const float* p = a.partial + (int64_t)b * a.nblk * a.C + c;
+    for (int i = 0; i < a.nblk; i++) s += p[(int64_t)i * a.C];
+    mean[c] = s * a.inv_hw;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int j = wave; j < a.sq; j += 4) {
+    float s = 0.f;
+    for (int c = lane; c < a.C; c += 64) s = fmaf(a.wr[(int64_t)j * a.C + c], mean[c], s);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) hid[j] = swishf(s + a.br[j]);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < a.C; c += 256) {
+    float s = a.be[c];
+    for (int j = 0; j < a.sq; j++) s = fmaf(a.we[(int64_t)c * a.sq + j], hid[j], s);
+    a.scale[(int64_t)b * a.C + c] = sigmoidf(s);
+  }
+}
+void launch_se(const SeArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(se_kernel, dim3(a.B), dim3(256), (a.C + a.sq) * sizeof(float), s, a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// MaxPool2dStaticSamePadding(3,2): the pad value is ZERO, not -inf (reference
+// efficientnet/utils_extra.py:72-86), so windows that overhang the border take max(...,0).
+// ------------------------------------------------------------------------------------------------
+template <bool BF16>
+__global__ __launch_bounds__(256) void pool_kernel(PoolArgs a) {
+  const int CG = a.C >> 3;
+  const int64_t total = (int64_t)a.B * a.Ho * a.Wo * CG;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int cg = (int)(idx % CG);
+  int64_t p = idx / CG;
+  const int ox = (int)(p % a.Wo); p /= a.Wo;
+  const int oy = (int)(p % a.Ho);
+  const int b = (int)(p / a.Ho);
+  float m[8];
+  bool first = true;
+#pragma unroll
+  for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+    for (int kx = 0; kx < 3; kx++) {
+      const int iy = oy * 2 - a.pad_t + ky, ix = ox * 2 - a.pad_l + kx;
+      float x[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
+        Vec8<BF16>::load(a.in, (((int64_t)b * a.H + iy) * a.W + ix) * a.C + cg * 8, x);
+#pragma unroll
+      for (int c = 0; c < 8; c++) m[c] = first ? x[c] : fmaxf(m[c], x[c]);
+      first = false;
+    }
+  Vec8<BF16>::store(a.out, idx * 8, m);
+}
+void launch_pool(const PoolArgs& a, hipStream_t s) {
+  const int64_t total = (int64_t)a.B * a.Ho * a.Wo * (a.C >> 3);
+  dim3 grid((unsigned)((total + 255) / 256));
+  if (a.bf16) hipLaunchKernelGGL(pool_kernel<true>, grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(pool_kernel<false>, grid, dim3(256), 0, s, a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// feature export: NHWC (dtype) -> NCHW fp32, the layout `features` has in the reference
+// (backbone.py:125) and in the ONNX outputs feat1..feat5.
+// ------------------------------------------------------------------------------------------------
+template <bool BF16>
+__global__ __launch_bounds__(256) void export_kernel(ExportArgs a) {
+  const int64_t total = (int64_t)a.B * a.C * a.H * a.W;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  int64_t p = idx;
+  const int x = (int)(p % a.W); p /= a.W;
+  const int y = (int)(p % a.H); p /= a.H;
+  const int c = (int)(p % a.C);
+  const int b = (int)(p / a.C);
+  const int64_t src = (((int64_t)b * a.H + y) * a.W + x) * a.C + c;
+  float v;
+  if (BF16) v = bf16_bits_to_f32(reinterpret_cast<const uint16_t*>(a.in)[src]);
+  else v = reinterpret_cast<const float*>(a.in)[src];
+  a.out[idx] = v;
+}
+void launch_export(const ExportArgs& a, hipStream_t s) {
+  const int64_t total = (int64_t)a.B * a.C * a.H * a.W;
+  dim3 grid((unsigned)((total + 255) / 256));
+  if (a.bf16) hipLaunchKernelGGL(export_kernel<true>, grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(export_kernel<false>, grid, dim3(256), 0, s, a);
+}

@@ -1,0 +1,166 @@
+// k_post.hip - decode half of the path on gfx950: box / translation decode and the
+// detection filter (score threshold -> greedy NMS -> first max_det survivors -> -1 padding).
+#include "hep_dev.h"
+#include "hep_internal.h"
+
+// ------------------------------------------------------------------------------------------------
+// format_bboxes + format_translation (reference hmdegopose/loss.py:12-51 ->
+// layers.py:117-249): deltas (ty,tx,th,tw); boxes clipped to [0,S-1];
+// Tx=(x/scale-px)*Tz/fx with Tz = raw_z*tz_scale.  Same fp32 operation order as the torch code
+// (no fma contraction across the reference's separate ops) so results agree to the last few ulps.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void decode_kernel(DecodeArgs a) {
+#pragma clang fp contract(off)
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)a.B * a.N) return;
+  const int n = (int)(idx % a.N), b = (int)(idx / a.N);
+  const f32x4 an = *reinterpret_cast<const f32x4*>(a.anchors + (int64_t)n * 4);
+  const f32x4 d = *reinterpret_cast<const f32x4*>(a.regression + idx * 4);
+  const float cxa = (an[0] + an[2]) / 2.f, cya = (an[1] + an[3]) / 2.f;
+  const float wa = an[2] - an[0], ha = an[3] - an[1];
+  const float ty = d[0], tx = d[1], th = d[2], tw = d[3];
+  const float w = expf(tw) * wa, h = expf(th) * ha;
+  const float cy = ty * ha + cya, cx = tx * wa + cxa;
+  f32x4 o;
+  o[0] = fminf(fmaxf(cx - w / 2.f, 0.f), a.clip_max);
+  o[1] = fminf(fmaxf(cy - h / 2.f, 0.f), a.clip_max);
+  o[2] = fminf(fmaxf(cx + w / 2.f, 0.f), a.clip_max);
+  o[3] = fminf(fmaxf(cy + h / 2.f, 0.f), a.clip_max);
+  *reinterpret_cast<f32x4*>(a.boxes + idx * 4) = o;
+
+  const float* ta = a.t_anchors + (int64_t)n * 3;
+  const float* r = a.translation_raw + idx * 3;
+  const float* cam = a.camera + (int64_t)b * 6;
+  const float stride = ta[2];
+  float x = ta[0] + r[0] * stride, y = ta[1] + r[1] * stride;
+  x = x / cam[5] - cam[2];
+  y = y / cam[5] - cam[3];
+  const float tz = r[2] * cam[4];
+  float* t = a.translation + idx * 3;
+  t[0] = x * tz / cam[0];
+  t[1] = y * tz / cam[1];
+  t[2] = tz;
+}
+void launch_decode(const DecodeArgs& a, hipStream_t s) {
+  const int64_t total = (int64_t)a.B * a.N;
+  hipLaunchKernelGGL(decode_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// filter_detections (reference hmdegopose/layers.py:264-400) for num_classes == 1, one workgroup
+// (1024 lanes) per image:
+//   1. key[n] = score>thr ? (score_bits << 32 | ~n) : 0      (positive floats order as integers)
+//   2. bitonic sort, descending: score desc, equal scores -> lower anchor index first
+//   3. greedy NMS over the sorted candidates in chunks of 1024: a candidate dies when its IoU
+//      with an already kept box is STRICTLY greater than nms_thr (TensorFlow semantics: plain
+//      areas, no +1); stop at max_det kept
+//   4. gather the survivors' rows, pad the rest with -1.
+// Index work is exact: the same anchors come out as from oracle/decode_ref.py bit for bit.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float iou_box(const f32x4 p, const f32x4 q) {
+#pragma clang fp contract(off)
+  const float ax0 = fminf(p[0], p[2]), ay0 = fminf(p[1], p[3]), ax1 = fmaxf(p[0], p[2]), ay1 = fmaxf(p[1], p[3]);
+  const float bx0 = fminf(q[0], q[2]), by0 = fminf(q[1], q[3]), bx1 = fmaxf(q[0], q[2]), by1 = fmaxf(q[1], q[3]);
+  const float aa = (ax1 - ax0) * (ay1 - ay0), ab = (bx1 - bx0) * (by1 - by0);
+  if (aa <= 0.f || ab <= 0.f) return 0.f;
+  const float iw = fmaxf(fminf(ax1, bx1) - fmaxf(ax0, bx0), 0.f);
+  const float ih = fmaxf(fminf(ay1, by1) - fmaxf(ay0, by0), 0.f);
+  const float inter = iw * ih;
+  return inter / ((aa + ab) - inter);
+}
+
+#define FILTER_THREADS 1024
+#define FILTER_MAX_DET 256
+__global__ __launch_bounds__(FILTER_THREADS) void filter_kernel(FilterArgs a) {
+  __shared__ f32x4 kept_box[FILTER_MAX_DET];
+  __shared__ int kept_idx[FILTER_MAX_DET];
+  __shared__ int s_nkept, s_next, s_done;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  uint64_t* keys = a.keys + (int64_t)b * a.npow2;
+  const float* scores = a.scores + (int64_t)b * a.N;
+  const f32x4* boxes = reinterpret_cast<const f32x4*>(a.boxes) + (int64_t)b * a.N;
+
+  for (int n = tid; n < a.npow2; n += FILTER_THREADS) {
+    uint64_t k = 0;
+    if (n < a.N) {
+      const float sc = scores[n];
+      if (sc > a.score_thr) k = ((uint64_t)__float_as_uint(sc) << 32) | (uint32_t)(~(uint32_t)n);
+    }
+    keys[n] = k;
+  }
+  __syncthreads();
+  for (int k = 2; k <= a.npow2; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < a.npow2; i += FILTER_THREADS) {
+        const int l = i ^ j;
+        if (l > i) {
+          const uint64_t x = keys[i], y = keys[l];
+          const bool desc = (i & k) == 0;
+          if (desc ? (x < y) : (x > y)) { keys[i] = y; keys[l] = x; }
+        }
+      }
+      __syncthreads();
+    }
+
+  if (tid == 0) { s_nkept = 0; s_done = 0; }
+  __syncthreads();
+  for (int base = 0; base < a.npow2; base += FILTER_THREADS) {
+    const uint64_t key = keys[base + tid];
+    bool alive = key != 0;
+    const int n = (int)(~(uint32_t)key);
+    f32x4 mine = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (alive) mine = boxes[n];
+    const int nk0 = s_nkept;
+    for (int j = 0; j < nk0 && alive; j++)
+      if (iou_box(mine, kept_box[j]) > a.nms_thr) alive = false;
+    int last = -1;   // chunk positions below `last` are resolved
+    while (true) {
+      __syncthreads();
+      if (tid == 0) s_next = FILTER_THREADS;
+      __syncthreads();
+      if (alive && tid > last) atomicMin(&s_next, tid);
+      __syncthreads();
+      const int nx = s_next;
+      if (nx >= FILTER_THREADS) break;
+      if (tid == nx) {
+        const int slot = s_nkept;
+        kept_box[slot] = mine; kept_idx[slot] = n;
+        s_nkept = slot + 1;
+        if (slot + 1 >= a.max_det) s_done = 1;
+        alive = false;
+      }
+      __syncthreads();
+      if (s_done) break;
+      if (alive && tid > nx && iou_box(mine, kept_box[s_nkept - 1]) > a.nms_thr) alive = false;
+      last = nx;
+    }
+    __syncthreads();
+    if (s_done || keys[min(base + FILTER_THREADS, a.npow2 - 1)] == 0) break;   // sorted: zeros only from here on
+  }
+  __syncthreads();
+  const int nk = s_nkept;
+  if (tid == 0) a.det_count[b] = nk;
+  for (int i = tid; i < a.max_det; i += FILTER_THREADS) {
+    const bool ok = i < nk;
+    const int n = ok ? kept_idx[i] : 0;
+    const int64_t row = (int64_t)b * a.max_det + i;
+    if (a.det_index) a.det_index[row] = ok ? n : -1;
+    if (a.det_scores) a.det_scores[row] = ok ? scores[n] : -1.f;
+    if (a.det_labels) a.det_labels[row] = ok ? 0 : -1;
+    if (a.det_boxes) {
+      const f32x4 bb = ok ? boxes[n] : (f32x4){-1.f, -1.f, -1.f, -1.f};
+      *reinterpret_cast<f32x4*>(a.det_boxes + row * 4) = bb;
+    }
+    const int64_t src = (int64_t)b * a.N + n;
+    if (a.det_rotation) for (int c = 0; c < 3; c++) a.det_rotation[row * 3 + c] = ok ? a.rotation[src * 3 + c] : -1.f;
+    if (a.det_translation) for (int c = 0; c < 3; c++) a.det_translation[row * 3 + c] = ok ? a.translation[src * 3 + c] : -1.f;
+  }
+  if (a.det_hand)
+    for (int i = tid; i < a.max_det * 63; i += FILTER_THREADS) {
+      const int d = i / 63, c = i % 63;
+      a.det_hand[((int64_t)b * a.max_det + d) * 63 + c] = d < nk ? a.hand[((int64_t)b * a.N + kept_idx[d]) * 63 + c] : -1.f;
+    }
+}
+void launch_filter(const FilterArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(filter_kernel, dim3(a.B), dim3(FILTER_THREADS), 0, s, a);
+}

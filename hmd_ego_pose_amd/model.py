@@ -1,0 +1,304 @@
+"""Host-side mirror of the reference's operator interface for the inference path.
+
+``HMDEgoPose`` has the reference's constructor, ``forward`` signature and ``state_dict``
+keys (pytorch-sandbox/backbone.py:13-16,104-125; key inventory in arch.param_spec), so
+``evaluate.py`` / ``main.py``-style drivers can build it, ``load_state_dict`` a checkpoint
+and call it.  In ``eval()`` on a ROCm device its forward is one call into ``libhep.so``
+(hand-written gfx950 kernels behind a C ABI, csrc/) through the ``torch.ops.hep.*`` custom
+ops below.  There is no other execution path: CPU tensors, training mode or a missing
+library raise - the reference's training graph is out of scope for this build.
+
+``TrainModelWithLoss`` mirrors the inference branch of pytorch-sandbox/train.py:23-85
+(forward -> anchors -> translation/box decode -> detection filter) on the GPU.
+"""
+from __future__ import annotations
+
+import ctypes
+import threading
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+from torch import nn
+
+from . import _capi
+from .arch import OUT_WIDTH, get_arch, level_sizes, num_anchors_total, param_spec
+from .weights import pack_bytes
+
+_PRECISIONS = {"fp32": _capi.HEP_F32, "f32": _capi.HEP_F32, "bf16": _capi.HEP_BF16}
+
+
+# --------------------------------------------------------------------------------------
+# session: one libhep handle for (weights, phi, size, max_batch, dtype, device)
+# --------------------------------------------------------------------------------------
+class Session:
+    """Owns a ``hep_handle``.  All tensors handed to it must live on ``device``."""
+
+    _registry: Dict[int, "Session"] = {}
+    _lock = threading.Lock()
+
+    def __init__(self, state_dict, phi: int, size: int, max_batch: int, precision: str = "fp32",
+                 device: Optional[torch.device] = None, flags: int = 0):
+        if precision not in _PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(_PRECISIONS)}")
+        if not torch.cuda.is_available():
+            raise _capi.HepError("no ROCm device visible: the MI355X path has no CPU fallback")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.phi, self.size, self.max_batch, self.precision = phi, size, max_batch, precision
+        blob = pack_bytes(state_dict)
+        h = ctypes.c_void_p()
+        _capi.check(_capi.lib().hep_create_from_memory(blob, len(blob), phi, size, max_batch, _PRECISIONS[precision],
+                                                       self.device.index or 0, flags, ctypes.byref(h)))
+        self.handle = h.value
+        self.num_anchors = _capi.lib().hep_num_anchors(self.handle)
+        self.fpn_w = get_arch(phi).fpn_w
+        self.levels = level_sizes(size)
+        with Session._lock:
+            Session._registry[self.handle] = self
+
+    def close(self):
+        if getattr(self, "handle", None):
+            with Session._lock:
+                Session._registry.pop(self.handle, None)
+            _capi.lib().hep_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- forward ----------------------------------------------------------------------
+    def forward(self, x: torch.Tensor, want_features: bool = True):
+        """x: fp32 [B,3,S,S] on the session's device, any strides.  Returns
+        (features|None, regression, classification, rotation, translation_raw, hand)."""
+        if not x.is_cuda or x.dtype != torch.float32 or x.dim() != 4 or x.shape[1] != 3 or x.shape[2] != self.size or x.shape[3] != self.size:
+            raise ValueError(f"expected a float32 ROCm tensor [B,3,{self.size},{self.size}], got {tuple(x.shape)} {x.dtype} on {x.device}")
+        B = x.shape[0]
+        N = self.num_anchors
+        outs = [torch.empty((B, N, k), dtype=torch.float32, device=x.device) for k in OUT_WIDTH]
+        feats = [torch.empty((B, self.fpn_w, s, s), dtype=torch.float32, device=x.device) for s in self.levels] if want_features else None
+        strides = (ctypes.c_int64 * 4)(*x.stride())
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        _capi.check(_capi.lib().hep_run_device(self.handle, x.data_ptr(), strides, B, _capi.ptr_array(outs),
+                                               _capi.ptr_array(feats) if feats else None, stream))
+        return (tuple(feats) if feats else None, *outs)
+
+    def decode(self, regression, translation_raw, camera):
+        B = regression.shape[0]
+        boxes = torch.empty((B, self.num_anchors, 4), dtype=torch.float32, device=regression.device)
+        trans = torch.empty((B, self.num_anchors, 3), dtype=torch.float32, device=regression.device)
+        cam = camera.to(regression.device, torch.float32).contiguous()
+        stream = torch.cuda.current_stream(regression.device).cuda_stream
+        _capi.check(_capi.lib().hep_decode_device(self.handle, regression.contiguous().data_ptr(), translation_raw.contiguous().data_ptr(),
+                                                  cam.data_ptr(), B, boxes.data_ptr(), trans.data_ptr(), stream))
+        return boxes, trans
+
+    def filter(self, boxes, classification, rotation, translation, hand, score_threshold=0.5, nms_threshold=0.5, max_detections=100):
+        B, dev, M = boxes.shape[0], boxes.device, max_detections
+        f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+        i = lambda *s: torch.empty(s, dtype=torch.int32, device=dev)
+        out = dict(boxes=f(B, M, 4), scores=f(B, M), labels=i(B, M), rotation=f(B, M, 3), translation=f(B, M, 3),
+                   hand=f(B, M, 63), index=i(B, M), count=i(B))
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        args = [t.contiguous() for t in (boxes, classification, rotation, translation, hand)]
+        _capi.check(_capi.lib().hep_filter_device(self.handle, *[t.data_ptr() for t in args], B, float(score_threshold),
+                                                  float(nms_threshold), M, *[out[k].data_ptr() for k in
+                                                                             ("boxes", "scores", "labels", "rotation", "translation", "hand", "index", "count")],
+                                                  stream))
+        return out
+
+    # -- introspection ------------------------------------------------------------------
+    def stage(self, name: str, batch: int) -> torch.Tensor:
+        """fp32 NHWC copy of a stage tensor of the last forward (needs FLAG_KEEP_INTERMEDIATES)."""
+        l = _capi.lib()
+        n = l.hep_debug_tensor_count(self.handle)
+        for i in range(n):
+            nm = ctypes.c_char_p(); dims = (ctypes.c_int64 * 4)()
+            l.hep_debug_tensor_info(self.handle, i, ctypes.byref(nm), dims)
+            if nm.value.decode() == name:
+                out = torch.empty((batch, dims[1], dims[2], dims[3]), dtype=torch.float32)
+                _capi.check(l.hep_debug_tensor(self.handle, name.encode(), batch, out.data_ptr(), out.numel()))
+                return out
+        raise KeyError(name)
+
+    def kernels(self, batch: int) -> List[Tuple[str, float, float]]:
+        l = _capi.lib()
+        out = []
+        for i in range(l.hep_kernel_count(self.handle, batch)):
+            nm = ctypes.c_char_p(); b = ctypes.c_double(); f = ctypes.c_double()
+            _capi.check(l.hep_kernel_info(self.handle, batch, i, ctypes.byref(nm), ctypes.byref(b), ctypes.byref(f)))
+            out.append((nm.value.decode(), b.value, f.value))
+        return out
+
+    def profile(self, batch: int, iters: int = 20, per_kernel: bool = False):
+        l = _capi.lib()
+        total = ctypes.c_float()
+        n = l.hep_kernel_count(self.handle, batch)
+        per = (ctypes.c_float * n)() if per_kernel else None
+        _capi.check(l.hep_profile(self.handle, batch, iters, ctypes.byref(total), per))
+        return total.value, (list(per) if per_kernel else None)
+
+
+# --------------------------------------------------------------------------------------
+# torch custom ops (the "PyTorch-ROCm custom op" face of the C ABI)
+# --------------------------------------------------------------------------------------
+def _session(handle: int) -> Session:
+    s = Session._registry.get(handle)
+    if s is None:
+        raise _capi.HepError("unknown libhep session handle")
+    return s
+
+
+@torch.library.custom_op("hep::forward", mutates_args=())
+def hep_forward(x: torch.Tensor, handle: int) -> List[torch.Tensor]:
+    return _forward_flat(x, handle)
+
+
+def _forward_flat(x, handle):
+    f, *outs = _session(handle).forward(x, want_features=True)
+    return list(f) + list(outs)
+
+
+@hep_forward.register_fake
+def _(x, handle):
+    s = _session(handle)
+    B = x.shape[0]
+    return [x.new_empty((B, s.fpn_w, l, l)) for l in s.levels] + [x.new_empty((B, s.num_anchors, k)) for k in OUT_WIDTH]
+
+
+@torch.library.custom_op("hep::decode", mutates_args=())
+def hep_decode(regression: torch.Tensor, translation_raw: torch.Tensor, camera: torch.Tensor, handle: int) -> List[torch.Tensor]:
+    return list(_session(handle).decode(regression, translation_raw, camera))
+
+
+@hep_decode.register_fake
+def _(regression, translation_raw, camera, handle):
+    return [torch.empty_like(regression), torch.empty_like(translation_raw)]
+
+
+# --------------------------------------------------------------------------------------
+# nn.Module drop-in
+# --------------------------------------------------------------------------------------
+class _Node(nn.Module):
+    """Plain container; the parameter tree only has to reproduce the reference's key names."""
+
+
+def _attach(root: nn.Module, key: str, shape: tuple):
+    *path, leaf = key.split(".")
+    m = root
+    for p in path:
+        if p not in m._modules:
+            m.add_module(p, _Node())
+        m = m._modules[p]
+    if leaf == "num_batches_tracked":
+        m.register_buffer(leaf, torch.zeros((), dtype=torch.int64))
+    elif leaf in ("running_mean", "running_var"):
+        m.register_buffer(leaf, torch.zeros(shape) if leaf == "running_mean" else torch.ones(shape))
+    else:
+        m.register_parameter(leaf, nn.Parameter(torch.zeros(shape)))
+
+
+class HMDEgoPose(nn.Module):
+    """Drop-in for ``backbone.HMDEgoPose`` on the MI355X inference path.
+
+    Same constructor arguments as the reference (backbone.py:13-16); extra keyword
+    ``precision`` = "fp32" (default: matches the reference within 1e-3) or "bf16".
+    """
+
+    def __init__(self, params, num_classes=1, compound_coef=0, load_weights=False, onnx_export=False,
+                 input_sizes=(512, 640, 768, 896, 1024, 1280, 1280, 1536, 1536), precision: str = "fp32", **kwargs):
+        super().__init__()
+        if int(params.get("iter", 0)) != 0:
+            raise ValueError("params['iter'] must be 0: the reference's iterative refinement sub-nets hard-code their input "
+                             "widths and are only usable with --iter=0 (hmdegopose/model.py:244,255-258; README.md:137,153)")
+        if load_weights:
+            raise ValueError("load_weights=True would download ImageNet weights; load a checkpoint with load_state_dict instead")
+        self.compound_coef = int(compound_coef)
+        self.num_classes = num_classes
+        self.onnx_export = onnx_export
+        self.input_sizes = list(input_sizes)
+        self.precision = precision
+        self.arch = get_arch(self.compound_coef)
+        for key, shape in param_spec(self.compound_coef, num_classes):
+            _attach(self, key, shape)
+        self.reset_parameters()
+        self._sessions: Dict[tuple, Session] = {}
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate())
+
+    def reset_parameters(self, seed: int = 0):
+        from .weights import seeded_state_dict
+        with torch.no_grad():
+            for k, v in seeded_state_dict(self.compound_coef, seed).items():
+                self.state_dict()[k].copy_(v)
+
+    def invalidate(self):
+        """Drop the packed device weights; they are rebuilt on the next forward.  Called after
+        load_state_dict; call it yourself after editing parameters in place."""
+        for s in getattr(self, "_sessions", {}).values():
+            s.close()
+        self._sessions = {}
+
+    def _apply(self, fn, *a, **kw):
+        out = super()._apply(fn, *a, **kw)
+        self.invalidate()
+        return out
+
+    def freeze_bn(self):
+        """BatchNorm is folded into the convolutions at pack time; nothing to freeze."""
+
+    def init_backbone(self, path):
+        state = torch.load(path, map_location="cpu")
+        try:
+            print(self.load_state_dict(state, strict=True))
+        except RuntimeError as e:
+            print("Ignoring " + str(e) + '"')
+
+    def session(self, size: int, batch: int, device: torch.device) -> Session:
+        key = (size, device.index, self.precision)
+        s = self._sessions.get(key)
+        if s is None or s.max_batch < batch:
+            if s is not None:
+                s.close()
+            mb = max(batch, 16) if s is None else max(batch, 2 * s.max_batch)
+            s = Session(self.state_dict(), self.compound_coef, size, mb, self.precision, device)
+            self._sessions[key] = s
+        return s
+
+    def forward(self, inputs: torch.Tensor):
+        if self.training:
+            raise RuntimeError("hmd_ego_pose_amd.HMDEgoPose is the MI355X inference path: call .eval() first "
+                               "(training through this module is not supported; use the reference for training)")
+        if not inputs.is_cuda:
+            raise RuntimeError("hmd_ego_pose_amd.HMDEgoPose runs on a ROCm device only (no CPU fallback): move the input with .cuda()")
+        x = inputs if inputs.dtype == torch.float32 else inputs.float()
+        s = self.session(int(x.shape[-1]), int(x.shape[0]), x.device)
+        flat = torch.ops.hep.forward(x, s.handle)
+        return tuple(flat[:5]), flat[5], flat[6], flat[7], flat[8], flat[9]
+
+
+class TrainModelWithLoss(nn.Module):
+    """Inference branch of the reference wrapper (train.py:23-40,72-85) on the GPU:
+    forward -> box/translation decode -> score threshold 0.5, NMS 0.5, top-100, -1 padding.
+
+    ``forward`` returns, like the reference, the six padded tensors of the LAST batch item
+    (layers.py:466-482 overwrites ``output`` per item) as CPU tensors; ``detect`` returns all
+    items on the device."""
+
+    def __init__(self, model: HMDEgoPose):
+        super().__init__()
+        self.model = model
+
+    @torch.no_grad()
+    def detect(self, imgs, camera_params, score_threshold=0.5, nms_threshold=0.5, max_detections=100):
+        _, regression, classification, rotation, translation_raw, hand = self.model(imgs)
+        s = self.model.session(int(imgs.shape[-1]), int(imgs.shape[0]), imgs.device)
+        boxes, translation = torch.ops.hep.decode(regression, translation_raw, camera_params.to(imgs.device), s.handle)
+        return s.filter(boxes, classification, rotation, translation, hand, score_threshold, nms_threshold, max_detections)
+
+    def forward(self, imgs, camera_params, is_losses=False, params=None, **kwargs):
+        if is_losses:
+            raise NotImplementedError("loss computation (train.py:42-70) is training-side and out of scope for the MI355X inference path")
+        d = self.detect(imgs, camera_params)
+        last = imgs.shape[0] - 1
+        return [d[k][last].cpu() for k in ("boxes", "scores", "labels", "rotation", "translation", "hand")]

@@ -1,0 +1,146 @@
+/* hep.h - C ABI of libhep.so, the MI355X-native (gfx950) EfficientPose / HMD-EgoPose
+ * inference path: EfficientNet-B{phi} MBConv backbone -> BiFPN -> box / class / rotation /
+ * translation / hand heads -> anchor, box and translation decode -> detection filter.
+ *
+ * Drop-in boundary.  Every entry point names the reference interface it replaces
+ * (paths relative to the reference repository root):
+ *
+ *   hep_create / hep_destroy   <- `new InferenceSession(ModelFilePath, sessionOptions)` / Dispose
+ *                                 unity-sandbox/OpenCVDNNSandboxNetCore/Program.cs:39-61,
+ *                                 unity-sandbox/WebRTCNetCoreSandbox/Program.cs:57-78;
+ *                                 Python: HMDEgoPose(...)+load_state_dict, pytorch-sandbox/evaluate.py:84-119
+ *   hep_run                    <- `Session.Run({"input": float[1,3,S,S]})` -> 10 outputs in the order fixed by
+ *                                 pytorch-sandbox/hmdegopose/misc_utils.py:77-83 (feat1..5, regression,
+ *                                 classification, rotation, translation_raw, hand); Program.cs:95-122 / :211-229
+ *   hep_run_device             <- HMDEgoPose.forward, pytorch-sandbox/backbone.py:104-125 (device tensors,
+ *                                 asynchronous on the caller's HIP stream; what the torch custom op calls)
+ *   hep_anchors                <- anchors_for_shape, pytorch-sandbox/generators/utils/anchors.py:273-318 and the
+ *                                 files anchors_256.txt / translation_anchors_256.txt the C# hosts load
+ *                                 (Program.cs:26-28)
+ *   hep_decode / _device       <- format_bboxes + format_translation, pytorch-sandbox/hmdegopose/loss.py:12-51
+ *                                 (C# twins Program.cs:225-470)
+ *   hep_filter / _device       <- FilterDetections / filter_detections, pytorch-sandbox/hmdegopose/layers.py:264-482
+ *                                 (C# twin Program.cs:472-627)
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 on success or a
+ * negative hep_status, never throws and never aborts; hep_last_error() gives a thread-local
+ * message.  A handle serialises its own calls with an internal mutex (the C# frame callback
+ * re-enters Run from WebRTC worker threads, Program.cs:128); several handles may coexist.
+ * There is NO CPU fallback: without a usable gfx950 device hep_create fails.
+ */
+#ifndef HEP_H_
+#define HEP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HEP_ABI_VERSION 1
+
+typedef struct hep_handle hep_handle;
+
+typedef enum hep_status {
+  HEP_OK = 0,
+  HEP_ERR_INVALID = -1,      /* bad argument                                  */
+  HEP_ERR_PACK = -2,         /* weight pack missing / malformed / wrong shape  */
+  HEP_ERR_DEVICE = -3,       /* HIP error or no gfx950 device                  */
+  HEP_ERR_UNSUPPORTED = -4   /* phi / size / batch outside the built range     */
+} hep_status;
+
+typedef enum hep_dtype {
+  HEP_F32 = 0,   /* fp32 storage, exact-fp32 MFMA (v_mfma_f32_16x16x4_f32): the parity mode        */
+  HEP_BF16 = 1   /* bf16 activations+weights, fp32 accumulate (v_mfma_f32_16x16x32_bf16): the bench */
+} hep_dtype;
+
+/* hep_create flags */
+#define HEP_FLAG_KEEP_INTERMEDIATES 1u   /* no activation-buffer reuse: hep_debug_tensor works for every stage */
+#define HEP_FLAG_NO_GRAPH 2u             /* launch kernels eagerly instead of replaying a captured hipGraph    */
+
+/* Output indices (the ONNX export order, misc_utils.py:77-83). */
+enum { HEP_OUT_FEAT1 = 0, HEP_OUT_FEAT5 = 4, HEP_OUT_REGRESSION = 5, HEP_OUT_CLASSIFICATION = 6,
+       HEP_OUT_ROTATION = 7, HEP_OUT_TRANSLATION_RAW = 8, HEP_OUT_HAND = 9, HEP_NUM_OUTPUTS = 10 };
+
+int hep_abi_version(void);
+const char* hep_last_error(void);
+
+/* Number of HIP devices visible; does not initialise the runtime beyond counting. */
+int hep_device_count(void);
+
+/* Build a session: reads a HEPW weight pack (the reference state_dict by name, fp32;
+ * see hmd_ego_pose_amd/weights.py), folds BatchNorm, lays weights out for the kernels
+ * and allocates the activation arena for batches up to max_batch on HIP device `device`. */
+int hep_create(const char* pack_path, int phi, int size, int max_batch, int dtype, int device,
+               unsigned flags, hep_handle** out);
+int hep_create_from_memory(const void* pack, size_t pack_bytes, int phi, int size, int max_batch,
+                           int dtype, int device, unsigned flags, hep_handle** out);
+void hep_destroy(hep_handle* h);
+
+/* Geometry. */
+int hep_num_anchors(const hep_handle* h);                       /* N = 9 * sum(level cells)          */
+int hep_output_shape(const hep_handle* h, int index, int batch, int64_t dims[4], int* ndim);
+
+/* Session.Run replacement: host buffers in, host buffers out, synchronous.
+ * input: fp32 NCHW [batch,3,S,S], already normalised.  feats may be NULL (or hold NULLs):
+ * feature maps are then not exported.  Outputs are caller-allocated, fp32:
+ * feats[l] NCHW [batch,W,s_l,s_l]; regression [batch,N,4]; classification [batch,N,1] (post-sigmoid);
+ * rotation [batch,N,3]; translation_raw [batch,N,3]; hand [batch,N,63]. */
+int hep_run(hep_handle* h, const float* input_nchw, int batch, float* const feats[5],
+            float* regression, float* classification, float* rotation, float* translation_raw, float* hand);
+
+/* HMDEgoPose.forward on device memory, asynchronous on `stream` (a hipStream_t; NULL = default).
+ * in_strides: element strides of (n,c,h,w) - an NHWC-memory view (eval/common.py:397) is accepted
+ * as is; NULL = contiguous NCHW.  outs[5] = regression, classification, rotation, translation_raw,
+ * hand (device, fp32, required).  feats may be NULL.  Re-running with the same pointers replays
+ * one hipGraph. */
+int hep_run_device(hep_handle* h, const float* input, const int64_t in_strides[4], int batch,
+                   float* const outs[5], float* const feats[5], void* stream);
+
+/* anchors_for_shape((size,size)): host, float64 arithmetic, one cast to float32.
+ * anchors [N,4] x1,y1,x2,y2; translation_anchors [N,3] cx,cy,stride.  Either may be NULL.
+ * Returns N (or a negative status). */
+int hep_anchors(int size, float* anchors, float* translation_anchors);
+
+/* Box + translation decode.  camera [batch,6] = fx,fy,px,py,tz_scale,image_scale.
+ * boxes [batch,N,4] = xmin,ymin,xmax,ymax clipped to [0,S-1]; translation [batch,N,3] = Tx,Ty,Tz. */
+int hep_decode(hep_handle* h, const float* regression, const float* translation_raw, const float* camera,
+               int batch, float* boxes, float* translation);
+int hep_decode_device(hep_handle* h, const float* regression, const float* translation_raw, const float* camera,
+                      int batch, float* boxes, float* translation, void* stream);
+
+/* Detection filter per image: score > score_threshold -> greedy NMS (IoU strictly greater than
+ * nms_threshold suppresses; candidates by descending score, ties by lower anchor index) -> first
+ * max_detections survivors -> rows padded with -1.  Unlike the reference (which returns only the
+ * last batch item, layers.py:466-482) every image gets its rows.
+ * det_boxes [batch,M,4], det_scores [batch,M], det_labels [batch,M] (int32), det_rotation [batch,M,3],
+ * det_translation [batch,M,3], det_hand [batch,M,63], det_index [batch,M] (int32 anchor index),
+ * det_count [batch] (int32).  Any output except det_count may be NULL. */
+int hep_filter(hep_handle* h, const float* boxes, const float* classification, const float* rotation,
+               const float* translation, const float* hand, int batch, float score_threshold,
+               float nms_threshold, int max_detections, float* det_boxes, float* det_scores,
+               int32_t* det_labels, float* det_rotation, float* det_translation, float* det_hand,
+               int32_t* det_index, int32_t* det_count);
+int hep_filter_device(hep_handle* h, const float* boxes, const float* classification, const float* rotation,
+                      const float* translation, const float* hand, int batch, float score_threshold,
+                      float nms_threshold, int max_detections, float* det_boxes, float* det_scores,
+                      int32_t* det_labels, float* det_rotation, float* det_translation, float* det_hand,
+                      int32_t* det_index, int32_t* det_count, void* stream);
+
+/* Introspection used by tests, bench.py and DESIGN.md tables. */
+int hep_debug_tensor_count(const hep_handle* h);
+int hep_debug_tensor_info(const hep_handle* h, int i, const char** name, int64_t dims[4] /* B,H,W,C */);
+/* Copy stage tensor `name` of the last run (as fp32, NHWC) into host memory. */
+int hep_debug_tensor(hep_handle* h, const char* name, int batch, float* out, size_t capacity_floats);
+int hep_kernel_count(const hep_handle* h, int batch);      /* launches in one forward                      */
+/* Per-launch description of the forward plan: name, algorithmic bytes and flops for `batch`. */
+int hep_kernel_info(const hep_handle* h, int batch, int i, const char** name, double* bytes, double* flops);
+/* Time `iters` replays of the forward at `batch` with HIP events on the handle's own stream; when
+ * per_kernel_ms is non-NULL (length hep_kernel_count) also time every launch eagerly, one by one. */
+int hep_profile(hep_handle* h, int batch, int iters, float* total_ms_per_iter, float* per_kernel_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HEP_H_ */
