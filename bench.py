@@ -1,0 +1,157 @@
+#!/usr/bin/env python3
+"""bench.py - frames/sec of the MI355X EfficientPose path at 256x256, batch 16 per GPU, phi 0.
+
+    python bench.py [--gpus N --steps K --warmup W]           (N=1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the hot path over one batch of 16 synthetic, HBM-resident frames per
+GPU: the full forward (stem .. heads, one hipGraph replay) + box/translation decode, through
+the C ABI of libhep.so.  Weak scaling: every rank owns 16 frames, the forward needs no
+collective (frames are independent); ranks meet only at the timing barriers.  Rank 0 prints
+ONE JSON line.  At N=1 it also carries
+  roofline      the dominant device function: algorithmic bytes per launch / its in-sequence
+                launch duration measured here with HIP events, against 8 TB/s HBM3E
+  cpu_baseline  the CPU oracle (torch fp32 restatement of the reference) timed on the host
+                cores in the evaluate.py regime (batch 1, anchors rebuilt per call, decode).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+METRIC = "frames/sec at 256x256 bs16 EfficientPose-phi0; ADD(-S) vs ref"
+HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (spec); ~6.3 TB/s achievable
+
+
+def cpu_baseline(phi, size, budget_s=15.0):
+    """The oracle, on the host cores, exactly in the reference's evaluate.py regime: one frame per
+    call, anchors regenerated every call (train.py:36), box + translation decode; no_grad is used
+    (the reference does not) - see BASELINE.md section 4."""
+    import numpy as np
+    import torch
+    from hmd_ego_pose_amd.weights import seeded_state_dict
+    from oracle import decode_ref as D
+    from oracle import efficientpose_ref as R
+    sd = seeded_state_dict(phi, 0)
+    rng = np.random.Generator(np.random.PCG64(0))
+    x = torch.from_numpy(rng.standard_normal((1, 3, size, size)).astype(np.float32))
+    cam = np.array([[480, 480, 128, 128, 1000, 1.0]], np.float32)
+
+    def one():
+        _, reg, cls, rot, trn, hand = R.forward(sd, x, phi)
+        anchors, t_anchors = D.anchors_for_size(size)
+        D.decode_boxes(anchors, reg.numpy(), size)
+        D.decode_translation(t_anchors, trn.numpy(), cam)
+
+    for _ in range(3):
+        one()
+    n, t0 = 0, time.perf_counter()
+    while True:
+        one(); n += 1
+        el = time.perf_counter() - t0
+        if (el >= budget_s and n >= 20) or n >= 2000:
+            break
+    return {"value": round(n / el, 3), "unit": "frames/s", "cores": int(torch.get_num_threads()), "kind": "port",
+            "sample": f"{n} frames, batch 1 per call (evaluate.py regime), phi {phi} {size}x{size} fp32, "
+                      f"forward + anchors + box/translation decode, {el:.1f} s on {os.cpu_count()} host CPUs"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=16, help="frames per GPU per step")
+    ap.add_argument("--phi", type=int, default=0)
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    from hmd_ego_pose_amd import _capi, dist as hd
+    from hmd_ego_pose_amd.model import Session
+    from hmd_ego_pose_amd.weights import seeded_state_dict
+
+    rank, local_rank, world = hd.init("nccl")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the product path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    B, S, phi = args.batch, args.size, args.phi
+
+    # weights: synthetic (no checkpoint ships with the reference), rank 0's copy broadcast once over RCCL
+    sd = hd.broadcast_state_dict(seeded_state_dict(phi, 0), dev)
+    sess = Session(sd, phi, S, B, args.precision, dev)
+    lib = _capi.lib()
+    N = sess.num_anchors
+    rng = np.random.Generator(np.random.PCG64(1000 + rank))
+    x = torch.from_numpy(rng.standard_normal((B, 3, S, S)).astype(np.float32)).to(dev)      # resident in HBM
+    cam = torch.tensor([[480, 480, 128, 128, 1000, 1.0]] * B, dtype=torch.float32, device=dev)
+    boxes = torch.empty((B, N, 4), dtype=torch.float32, device=dev)
+    trans = torch.empty((B, N, 3), dtype=torch.float32, device=dev)
+    strides = (ctypes.c_int64 * 4)(*x.stride())
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def step():
+        # forward into the handle's own output buffers (no copies), then decode from them
+        _capi.check(lib.hep_run_device(sess.handle, x.data_ptr(), strides, B, None, None, stream))
+        _capi.check(lib.hep_decode_device(sess.handle, None, None, cam.data_ptr(), B, boxes.data_ptr(), trans.data_ptr(), stream))
+
+    for _ in range(args.warmup):
+        step()
+    hd.barrier(); torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(dev); hd.barrier()
+    elapsed = hd.max_over_ranks(time.perf_counter() - t0, dev)
+    assert torch.isfinite(boxes).all() and torch.isfinite(trans).all()
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        out = {
+            "metric": METRIC, "value": round(B * world * args.steps / elapsed, 2), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": f"EfficientPose phi={phi} {S}x{S} {args.precision} batch={B} per GPU: forward (stem, MBConv, BiFPN, 5 heads) "
+                                   f"+ box/translation decode; seeded random-init weights, N(0,1) frames resident in HBM",
+                       "phi": phi, "size": S, "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
+                       "anchors": N, "launches_per_step": len(sess.kernels(B)) + 1},
+        }
+        if world == 1:
+            total_ms, per = sess.profile(B, 30, per_kernel=True)
+            ks = sess.kernels(B)
+            agg = {}
+            for (name, nbytes, flops, sym), t in zip(ks, per):
+                a = agg.setdefault(sym, [0.0, 0.0, 0.0, 0])
+                a[0] += t; a[1] += nbytes; a[2] += flops; a[3] += 1
+            sym, (t, nbytes, flops, calls) = max(agg.items(), key=lambda kv: kv[1][0])
+            achieved = nbytes / (t * 1e-3) / 1e9
+            out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                               "kernel": sym, "launches_per_step": calls, "avg_launch_us": round(t / calls * 1e3, 2),
+                               "algorithmic_bytes_per_launch": round(nbytes / calls), "share_of_step": round(t / sum(per), 3),
+                               "graph_replay_ms": round(total_ms, 4),
+                               "end_to_end_frac": round(sum(k[1] for k in ks) / (total_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(phi, S)
+        print(json.dumps(out), flush=True)
+    sess.close()
+    if world > 1:
+        import torch.distributed as td
+        td.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -42,6 +42,7 @@ SYMBOLS = {
     "hep_debug_tensor": (c_int, [_P, c_char_p, c_int, _FP, c_size_t]),
     "hep_kernel_count": (c_int, [_P, c_int]),
     "hep_kernel_info": (c_int, [_P, c_int, c_int, POINTER(c_char_p), POINTER(c_double), POINTER(c_double)]),
+    "hep_kernel_symbol": (c_int, [_P, c_int, POINTER(c_char_p)]),
     "hep_profile": (c_int, [_P, c_int, c_int, POINTER(c_float), _FP]),
 }
 

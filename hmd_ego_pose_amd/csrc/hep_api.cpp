@@ -24,7 +24,7 @@ namespace hep {
 
 Session::~Session() {
   for (auto& g : graphs) hipGraphExecDestroy(g.second);
-  for (Op& o : ops) if (o.kind == OP_SEP && o.sep.segs) hipFree((void*)o.sep.segs);
+  for (Op& o : ops) if (o.kind == OP_SEP) { hipFree((void*)o.sep.segs); hipFree((void*)o.sep.tile_seg); }
   hipFree(d_weights); hipFree(d_arena);
   for (int i = 0; i < 5; i++) { hipFree(d_out[i]); hipFree(d_feat_nchw[i]); }
   hipFree(d_in); hipFree(d_anchors); hipFree(d_tanchors); hipFree(d_boxes); hipFree(d_trans); hipFree(d_cam);
@@ -372,6 +372,24 @@ int hep_kernel_info(const hep_handle* h, int batch, int i, const char** name, do
   return 0;
 }
 
+int hep_kernel_symbol(const hep_handle* h, int i, const char** symbol) {
+  if (!h || !symbol || i < 0 || i >= (int)h->s.ops.size()) return fail(HEP_ERR_INVALID, "bad kernel index");
+  static thread_local std::string buf;
+  const Op& o = h->s.ops[i];
+  const char* t = h->s.dtype ? "true" : "false";
+  char tmp[128];
+  switch (o.kind) {
+    case OP_STEM: snprintf(tmp, sizeof tmp, "stem_kernel<%s>", t); break;
+    case OP_PW: snprintf(tmp, sizeof tmp, "pw_gemm_kernel<%s, %d, %d, %d>", t, o.pw.mode == 0 ? o.pw.MT : 1, o.pw.NT, o.pw.mode); break;
+    case OP_DW: snprintf(tmp, sizeof tmp, "dw_kernel<%s, %d, %d, %d>", t, o.dw.k, o.dw.s, o.dw.TW); break;
+    case OP_SE: snprintf(tmp, sizeof tmp, "se_kernel"); break;
+    case OP_POOL: snprintf(tmp, sizeof tmp, "pool_kernel<%s>", t); break;
+    default: snprintf(tmp, sizeof tmp, "sep_kernel<%s>", t); break;
+  }
+  buf = tmp; *symbol = buf.c_str();
+  return 0;
+}
+
 int hep_profile(hep_handle* h, int batch, int iters, float* total_ms_per_iter, float* per_kernel_ms) {
   if (!h || iters < 1) return fail(HEP_ERR_INVALID, "bad argument");
   Session& s = h->s;
@@ -391,15 +409,25 @@ int hep_profile(hep_handle* h, int batch, int iters, float* total_ms_per_iter, f
   float ms = 0; HIPRET(hipEventElapsedTime(&ms, e0, e1));
   if (total_ms_per_iter) *total_ms_per_iter = ms / iters;
   if (per_kernel_ms) {
-    for (size_t k = 0; k < s.ops.size(); k++) {
-      for (int w = 0; w < 2; w++) launch_op(s, s.ops[k], batch, s.stream, s.d_in, st);
-      HIPRET(hipEventRecord(e0, s.stream));
-      for (int i = 0; i < iters; i++) launch_op(s, s.ops[k], batch, s.stream, s.d_in, st);
-      HIPRET(hipEventRecord(e1, s.stream));
-      HIPRET(hipEventSynchronize(e1));
-      HIPRET(hipEventElapsedTime(&ms, e0, e1));
-      per_kernel_ms[k] = ms / iters;
+    // in-sequence timing: the forward is launched eagerly with an event in front of every kernel,
+    // so each duration is taken in its real context (cold caches, real predecessor), on the stream
+    // the kernel runs on.  It includes the inter-kernel boundary, like a hipGraph replay does.
+    const size_t n = s.ops.size();
+    std::vector<hipEvent_t> ev(n + 1);
+    for (auto& e : ev) HIPRET(hipEventCreate(&e));
+    std::vector<double> acc(n, 0.0);
+    for (int i = 0; i < iters + 1; i++) {
+      for (size_t k = 0; k < n; k++) {
+        HIPRET(hipEventRecord(ev[k], s.stream));
+        launch_op(s, s.ops[k], batch, s.stream, s.d_in, st);
+      }
+      HIPRET(hipEventRecord(ev[n], s.stream));
+      HIPRET(hipEventSynchronize(ev[n]));
+      if (i == 0) continue;     // first pass warms the instruction caches
+      for (size_t k = 0; k < n; k++) { HIPRET(hipEventElapsedTime(&ms, ev[k], ev[k + 1])); acc[k] += ms; }
     }
+    for (size_t k = 0; k < n; k++) per_kernel_ms[k] = (float)(acc[k] / iters);
+    for (auto& e : ev) hipEventDestroy(e);
   }
   hipEventDestroy(e0); hipEventDestroy(e1);
   return 0;

@@ -6,6 +6,7 @@
 #include <stdint.h>
 
 #define HEP_MAX_SRC 3
+#define SEP_MAX_TILES_N 12   // n-tiles (16 columns) per sepconv segment; wider layers are split into segments
 
 enum { ACT_NONE = 0, ACT_SWISH = 1, ACT_SIGMOID = 2 };
 enum { SRC_SAME = 1, SRC_UP = 2, SRC_DOWN = 3 };   // gather kinds of a BiFPN fusion input
@@ -28,6 +29,7 @@ struct PwArgs {
   int M, K, N, tilesN; // tilesN = ceil(N/16); W holds tilesN*16 rows
   int HW;              // rows per image (for se)
   int act, bf16, MT, NT;
+  int mode;            // wave arrangement inside a workgroup: 0 along M, 1 along N, 2 split-K (k_pw.hip)
 };
 
 // ---- depthwise kxk conv + folded BN + swish (+ per-block channel sums for SE) ----
@@ -40,7 +42,7 @@ struct DwArgs {
 // ---- squeeze-excite FCs: mean -> reduce(+swish) -> expand(+sigmoid) ----
 struct SeArgs {
   const float* partial; int nblk; float inv_hw;
-  const float* wr /*[sq][C]*/; const float* br; const float* we /*[C][sq]*/; const float* be;
+  const float* wr /*[sq][C]*/; const float* br; const float* we /*[sq][C] (transposed)*/; const float* be;
   float* scale;        // [B][C]
   int B, C, sq;
 };
@@ -61,10 +63,14 @@ struct SepSeg {
   int N, tilesN, act;
   void* out; int out_f32;                  // fp32 head outputs, otherwise dtype
   int64_t out_bstride, out_off, out_rowstride;   // elements: per image, level offset, per pixel
-  int col_kin, col_kout, col_off;          // column n -> (n/kin)*kout + n%kin + off
+  int col_kin, col_kout, col_off;          // column nn = n_base + n -> (nn/kin)*kout + nn%kin + off
+  int n_base;                              // first output column of this segment (wide headers are split)
   int tiles_x, tiles_y, tile_begin;        // 8x8 tiles; tile_begin = prefix over segments (incl. batch)
 };
-struct SepArgs { const SepSeg* segs; int nseg; int B; int total_tiles; int bf16; int C; size_t lds_bytes; };
+struct SepArgs {
+  const SepSeg* segs; const int* tile_seg;   // device tables: segments, and tile (blockIdx.x) -> segment
+  int nseg; int B; int total_tiles; int bf16; int C; size_t lds_bytes;
+};
 
 // ---- decode: boxes + translation from raw heads (loss.py:12-51) ----
 struct DecodeArgs {

@@ -248,9 +248,21 @@ struct Planner {
     o.pw.K = K; o.pw.N = N; o.pw.tilesN = tilesN; o.pw.HW = HW; o.pw.act = act; o.pw.bf16 = s->dtype;
     // tile shape: as many n-tiles per wave as fit (<= 8) so the activation rows are streamed
     // as few times as possible; two m-tiles per wave when the layer has rows to spare
-    const int chunks = (tilesN + 7) / 8;
-    o.pw.NT = (tilesN + chunks - 1) / chunks;
-    o.pw.MT = ((int64_t)HW * s->max_batch >= 16384 && o.pw.NT <= 4) ? 2 : 1;
+    {
+      const int64_t Mmax = (int64_t)HW * s->max_batch;
+      const int64_t strips = (Mmax + 15) / 16;             // 16-row strips
+      const int ksteps = (K + (s->dtype ? 32 : 16) - 1) / (s->dtype ? 32 : 16);
+      auto clampi = [](int64_t v, int lo, int hi) { return (int)std::max<int64_t>(lo, std::min<int64_t>(hi, v)); };
+      if (Mmax >= 16384) {          // big maps: waves along M, >= 256 workgroups anyway
+        const int chunks = (tilesN + 7) / 8;
+        o.pw.mode = 0; o.pw.NT = (tilesN + chunks - 1) / chunks;
+        o.pw.MT = (Mmax >= 65536 && o.pw.NT <= 4) ? 2 : 1;
+      } else if (ksteps >= 8) {     // small maps, deep K (project): split K over the 4 waves
+        o.pw.mode = 2; o.pw.MT = 1; o.pw.NT = clampi(strips * tilesN / 256, 1, std::min(8, tilesN));
+      } else {                      // small maps, wide N (expand / lateral): waves side by side in N
+        o.pw.mode = 1; o.pw.MT = 1; o.pw.NT = clampi(strips * tilesN / (4 * 256), 1, std::min(8, (tilesN + 3) / 4));
+      }
+    }
     wref(op, F_PW_W, wb.put_typed(wf)); wref(op, F_PW_B, wb.put_f32(bf));
     tref(op, F_PW_A, in_t, false); tref(op, F_PW_OUT, out_t, true);
     if (se_t >= 0) tref(op, F_PW_SE, se_t, false);
@@ -314,7 +326,9 @@ struct Planner {
       o.se.nblk = bpi; o.se.inv_hw = 1.0f / (float)(Ho * Wo); o.se.C = b.cexp; o.se.sq = b.se;
       wref(op, F_SE_WR, wb.put_f32(std::vector<float>(wr->data, wr->data + wr->count)));
       wref(op, F_SE_BR, wb.put_f32(std::vector<float>(br->data, br->data + br->count)));
-      wref(op, F_SE_WE, wb.put_f32(std::vector<float>(we->data, we->data + we->count)));
+      std::vector<float> wet((size_t)b.cexp * b.se);   // [sq][C]: the expand FC reads coalesced rows
+      for (int c = 0; c < b.cexp; c++) for (int j = 0; j < b.se; j++) wet[(size_t)j * b.cexp + c] = we->data[(size_t)c * b.se + j];
+      wref(op, F_SE_WE, wb.put_f32(wet));
       wref(op, F_SE_BE, wb.put_f32(std::vector<float>(be->data, be->data + be->count)));
       tref(op, F_SE_PART, part_t, false); tref(op, F_SE_SCALE, scale_t, true);
       o.act_bytes_per_image = ((double)bpi * b.cexp + b.cexp) * 4;
@@ -342,20 +356,12 @@ struct Planner {
   void add_sep(const std::string& name, const std::vector<SegSpec>& specs) {
     const int C = s->arch.fpn_w;
     const int op = new_op(OP_SEP, name);
-    s->ops[op].segs.resize(specs.size());
     int tile_begin = 0;
     double bytes = 0, flops = 0, wbytes = 0;
+    const int chunk_cols = SEP_MAX_TILES_N * 16;
     for (size_t i = 0; i < specs.size(); i++) {
       const SegSpec& sp = specs[i];
-      SepSeg sg; memset(&sg, 0, sizeof sg);
       const int hw = s->levels[sp.level];
-      sg.h = hw; sg.w = hw; sg.C = C; sg.nsrc = sp.nsrc; sg.pre_act = sp.pre_act;
-      for (int j = 0; j < sp.nsrc; j++) {
-        const TensorDesc& t = s->tensors[sp.src[j]];
-        sg.kind[j] = sp.kind[j]; sg.fw[j] = sp.fw[j]; sg.sh[j] = t.H; sg.sw[j] = t.W;
-        int pb, pa; same_pad(t.H, 3, 2, &pb, &pa); sg.pool_pad[j] = pb;
-        bytes += (double)t.H * t.W * C * es();
-      }
       const PackTensor* wd = get(sp.key + ".depthwise_conv.conv.weight", {C, 1, 3, 3});
       const PackTensor* wp = get(sp.key + ".pointwise_conv.conv.weight", {sp.N, C, 1, 1});
       const PackTensor* bp = get(sp.key + ".pointwise_conv.conv.bias", {sp.N});
@@ -363,36 +369,47 @@ struct Planner {
       if (!ok) return;
       std::vector<float> wdw((size_t)9 * C);
       for (int c = 0; c < C; c++) for (int t = 0; t < 9; t++) wdw[(size_t)t * C + c] = wd->data[(size_t)c * 9 + t];
-      const int tilesN = (sp.N + 15) / 16;
-      std::vector<float> wf((size_t)tilesN * 16 * C, 0.f), bf((size_t)tilesN * 16, 0.f);
-      for (int n = 0; n < sp.N; n++) {
-        const float sc = sp.bn.empty() ? 1.f : bn.scale[n], sh = sp.bn.empty() ? 0.f : bn.shift[n];
-        for (int k = 0; k < C; k++) wf[(size_t)n * C + k] = wp->data[(size_t)n * C + k] * sc;
-        bf[n] = bp->data[n] * sc + sh;
-      }
-      sg.N = sp.N; sg.tilesN = tilesN; sg.act = sp.act;
-      sg.tiles_x = (hw + 7) / 8; sg.tiles_y = (hw + 7) / 8; sg.tile_begin = tile_begin;
-      tile_begin += sg.tiles_x * sg.tiles_y;
-      if (sp.out_t >= 0) {
-        sg.out_f32 = 0; sg.out_bstride = (int64_t)hw * hw * sp.N; sg.out_off = 0; sg.out_rowstride = sp.N;
-        sg.col_kin = 1; sg.col_kout = 1; sg.col_off = 0;
-        bytes += (double)hw * hw * sp.N * es();
-      } else {
-        sg.out_f32 = 1; sg.out_bstride = (int64_t)s->num_anchors * sp.out_k; sg.out_off = (int64_t)s->level_off[sp.level] * sp.out_k;
-        sg.out_rowstride = 9 * sp.out_k; sg.col_kin = sp.col_kin; sg.col_kout = sp.col_kout; sg.col_off = sp.col_off;
-        bytes += (double)hw * hw * sp.N * 4;
-      }
+      const size_t wdw_off = wb.put_f32(wdw);
+      for (int j = 0; j < sp.nsrc; j++) bytes += (double)s->tensors[sp.src[j]].H * s->tensors[sp.src[j]].W * C * es();
+      bytes += (double)hw * hw * sp.N * (sp.out_t >= 0 ? es() : 4.0);
       flops += 2.0 * 9 * hw * hw * C + 2.0 * hw * hw * C * sp.N;
       wbytes += (double)sp.N * C * es() + 9.0 * C * 4;
-      s->ops[op].segs[i] = sg;
-      wref(op, F_SEG_WDW, wb.put_f32(wdw), (int)i); wref(op, F_SEG_WPW, wb.put_typed(wf), (int)i);
-      wref(op, F_SEG_BIAS, wb.put_f32(bf), (int)i);
-      for (int j = 0; j < sp.nsrc; j++) tref(op, F_SEG_SRC, sp.src[j], false, (int)i, j);
-      if (sp.out_t >= 0) tref(op, F_SEG_OUT, sp.out_t, true, (int)i);
-      else refs.push_back({op, F_SEG_OUT, (int)i, 0, 0, -(sp.head_out + 2)});   // encoded head output
+      for (int n0 = 0; n0 < sp.N; n0 += chunk_cols) {        // wide headers: one segment per 192 columns
+        const int Nc = std::min(chunk_cols, sp.N - n0);
+        SepSeg sg; memset(&sg, 0, sizeof sg);
+        sg.h = hw; sg.w = hw; sg.C = C; sg.nsrc = sp.nsrc; sg.pre_act = sp.pre_act;
+        for (int j = 0; j < sp.nsrc; j++) {
+          const TensorDesc& t = s->tensors[sp.src[j]];
+          sg.kind[j] = sp.kind[j]; sg.fw[j] = sp.fw[j]; sg.sh[j] = t.H; sg.sw[j] = t.W;
+          int pb, pa; same_pad(t.H, 3, 2, &pb, &pa); sg.pool_pad[j] = pb;
+        }
+        const int tilesN = (Nc + 15) / 16;
+        std::vector<float> wf((size_t)tilesN * 16 * C, 0.f), bf((size_t)tilesN * 16, 0.f);
+        for (int n = 0; n < Nc; n++) {
+          const float sc = sp.bn.empty() ? 1.f : bn.scale[n0 + n], sh = sp.bn.empty() ? 0.f : bn.shift[n0 + n];
+          for (int k = 0; k < C; k++) wf[(size_t)n * C + k] = wp->data[(size_t)(n0 + n) * C + k] * sc;
+          bf[n] = bp->data[n0 + n] * sc + sh;
+        }
+        sg.N = Nc; sg.tilesN = tilesN; sg.act = sp.act; sg.n_base = n0;
+        sg.tiles_x = (hw + 7) / 8; sg.tiles_y = (hw + 7) / 8; sg.tile_begin = tile_begin;
+        tile_begin += sg.tiles_x * sg.tiles_y;
+        if (sp.out_t >= 0) {
+          sg.out_f32 = 0; sg.out_bstride = (int64_t)hw * hw * sp.N; sg.out_off = n0; sg.out_rowstride = sp.N;
+          sg.col_kin = 1; sg.col_kout = 1; sg.col_off = 0;
+        } else {
+          sg.out_f32 = 1; sg.out_bstride = (int64_t)s->num_anchors * sp.out_k; sg.out_off = (int64_t)s->level_off[sp.level] * sp.out_k;
+          sg.out_rowstride = 9 * sp.out_k; sg.col_kin = sp.col_kin; sg.col_kout = sp.col_kout; sg.col_off = sp.col_off;
+        }
+        s->ops[op].segs.push_back(sg);
+        const int si = (int)s->ops[op].segs.size() - 1;
+        wref(op, F_SEG_WDW, wdw_off, si); wref(op, F_SEG_WPW, wb.put_typed(wf), si); wref(op, F_SEG_BIAS, wb.put_f32(bf), si);
+        for (int j = 0; j < sp.nsrc; j++) tref(op, F_SEG_SRC, sp.src[j], false, si, j);
+        if (sp.out_t >= 0) tref(op, F_SEG_OUT, sp.out_t, true, si);
+        else refs.push_back({op, F_SEG_OUT, si, 0, 0, -(sp.head_out + 2)});   // encoded head output
+      }
     }
     Op& o = s->ops[op];
-    o.sep.nseg = (int)specs.size(); o.sep.total_tiles = tile_begin; o.sep.bf16 = s->dtype; o.sep.C = C;
+    o.sep.nseg = (int)o.segs.size(); o.sep.total_tiles = tile_begin; o.sep.bf16 = s->dtype; o.sep.C = C;
     o.sep.lds_bytes = sep_lds_bytes(C, s->dtype);
     o.act_bytes_per_image = bytes; o.flops_per_image = flops; o.weight_bytes = wbytes;
   }
@@ -650,6 +667,12 @@ int build_session(Session* s, const Pack& pack, std::string* err) {
       SepSeg* d; HIPCHK(hipMalloc((void**)&d, o.segs.size() * sizeof(SepSeg)));
       HIPCHK(hipMemcpy(d, o.segs.data(), o.segs.size() * sizeof(SepSeg), hipMemcpyHostToDevice));
       o.sep.segs = d;
+      std::vector<int> tile_seg(o.sep.total_tiles);
+      for (size_t si = 0; si < o.segs.size(); si++)
+        for (int t = 0; t < o.segs[si].tiles_x * o.segs[si].tiles_y; t++) tile_seg[o.segs[si].tile_begin + t] = (int)si;
+      int* dt; HIPCHK(hipMalloc((void**)&dt, tile_seg.size() * sizeof(int)));
+      HIPCHK(hipMemcpy(dt, tile_seg.data(), tile_seg.size() * sizeof(int), hipMemcpyHostToDevice));
+      o.sep.tile_seg = dt;
     }
 #undef HIPCHK
   return 0;

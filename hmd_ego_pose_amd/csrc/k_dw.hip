@@ -177,38 +177,59 @@ void launch_dw(const DwArgs& a, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 // squeeze-excite: mean over HW (from the per-block partial sums) -> reduce FC + swish ->
 // expand FC + sigmoid -> scale[b][c]; replaces `_se_reduce,_swish,_se_expand,sigmoid`
-// (reference efficientnet/model.py:90-93).  fp32 throughout; one block per image.  The scale is
-// applied by the project GEMM while it loads its A fragments.
+// (reference efficientnet/model.py:90-93).  fp32 throughout.  grid = (B, SE_SPLIT): every block
+// rebuilds the mean and the hidden vector (cheap, L2-resident) and produces one slice of the
+// channels, so the launch is SE_SPLIT x B blocks of 16 waves instead of B serial chains.  All
+// loads of a phase are independent and issued before their first use; `we` is stored [sq][C] so
+// the expand FC reads coalesced rows.  The scale is applied by the project GEMM while it loads
+// its A fragments.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void se_kernel(SeArgs a) {
+#define SE_THREADS 1024
+#define SE_SPLIT 4
+__global__ __launch_bounds__(SE_THREADS) void se_kernel(SeArgs a) {
   extern __shared__ float sm[];          // mean[C] | hidden[sq]
   float* mean = sm;
   float* hid = sm + a.C;
   const int b = blockIdx.x;
-  for (int c = threadIdx.x; c < a.C; c += 256) {
-    float s = 0.f;
+  for (int c = threadIdx.x; c < a.C; c += SE_THREADS) {
     const float* p = a.partial + (int64_t)b * a.nblk * a.C + c;
-    for (int i = 0; i < a.nblk; i++) s += p[(int64_t)i * a.C];
-    mean[c] = s * a.inv_hw;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int i = 0;
+    for (; i + 4 <= a.nblk; i += 4) {
+      s0 += p[(int64_t)i * a.C]; s1 += p[(int64_t)(i + 1) * a.C]; s2 += p[(int64_t)(i + 2) * a.C]; s3 += p[(int64_t)(i + 3) * a.C];
+    }
+    for (; i < a.nblk; i++) s0 += p[(int64_t)i * a.C];
+    mean[c] = ((s0 + s1) + (s2 + s3)) * a.inv_hw;
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int j = wave; j < a.sq; j += 4) {
+  for (int j = wave; j < a.sq; j += SE_THREADS / 64) {
+    const float* wr = a.wr + (int64_t)j * a.C;
     float s = 0.f;
-    for (int c = lane; c < a.C; c += 64) s = fmaf(a.wr[(int64_t)j * a.C + c], mean[c], s);
+    for (int c = lane * 4; c < a.C; c += 256) {   // C is a multiple of 8
+      const f32x4 w = *reinterpret_cast<const f32x4*>(wr + c);
+      s += w[0] * mean[c] + w[1] * mean[c + 1] + w[2] * mean[c + 2] + w[3] * mean[c + 3];
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     if (lane == 0) hid[j] = swishf(s + a.br[j]);
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < a.C; c += 256) {
-    float s = a.be[c];
-    for (int j = 0; j < a.sq; j++) s = fmaf(a.we[(int64_t)c * a.sq + j], hid[j], s);
-    a.scale[(int64_t)b * a.C + c] = sigmoidf(s);
+  const int per = (a.C + SE_SPLIT - 1) / SE_SPLIT;
+  const int c0 = blockIdx.y * per, c1 = min(a.C, c0 + per);
+  for (int c = c0 + threadIdx.x; c < c1; c += SE_THREADS) {
+    float s0 = a.be[c], s1 = 0.f;
+    int j = 0;
+    for (; j + 2 <= a.sq; j += 2) {
+      s0 = fmaf(a.we[(int64_t)j * a.C + c], hid[j], s0);
+      s1 = fmaf(a.we[(int64_t)(j + 1) * a.C + c], hid[j + 1], s1);
+    }
+    if (j < a.sq) s0 = fmaf(a.we[(int64_t)j * a.C + c], hid[j], s0);
+    a.scale[(int64_t)b * a.C + c] = sigmoidf(s0 + s1);
   }
 }
 void launch_se(const SeArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(se_kernel, dim3(a.B), dim3(256), (a.C + a.sq) * sizeof(float), s, a);
+  hipLaunchKernelGGL(se_kernel, dim3(a.B, SE_SPLIT), dim3(SE_THREADS), (a.C + a.sq) * sizeof(float), s, a);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -13,106 +13,153 @@
 // (lane l: row l&15, k = 8*(l>>4)+j), and each lane ends with 4 CONSECUTIVE output channels of
 // one pixel -> one 8/16-byte store.  bf16: v_mfma_f32_16x16x32_bf16; fp32 (parity mode):
 // v_mfma_f32_16x16x4_f32, an exact fp32 fma chain (4 k per issue, fed from the same 16-byte loads).
-// A wave owns MT x NT tiles of 16x16; a block is 4 waves stacked along M.
+//
+// These GEMMs are small and skinny (M = 1 Ki..256 Ki rows, K and N = 16..1152), i.e. latency- and
+// HBM-bound, never MFMA-bound; what matters is enough workgroups and enough loads in flight.  A
+// workgroup is 4 waves that the plan arranges per layer (PwArgs::mode):
+//   mode 0  waves stacked along M   (big feature maps: each wave MT x NT tiles of 16x16)
+//   mode 1  waves side by side in N (expand layers on small maps: one 16-row strip, 4*NT n-tiles)
+//   mode 2  waves split K           (project layers on small maps: partial sums meet in LDS)
+// The K loop is software-pipelined one step ahead (fragments of step k+1 are in flight while
+// step k feeds the MFMAs).
 #include "hep_dev.h"
 #include "hep_internal.h"
 
+template <bool BF16> struct Frag;
+template <> struct Frag<true> { typedef u32x4 raw; static constexpr int KSTEP = 32, KLANE = 8; };
+template <> struct Frag<false> { typedef f32x4 raw; static constexpr int KSTEP = 16, KLANE = 4; };
+
 template <bool BF16, int MT, int NT>
+struct Step {
+  typename Frag<BF16>::raw a[MT];   // activation fragments
+  f32x4 s0[MT], s1[MT];             // squeeze-excite scales for them
+  typename Frag<BF16>::raw w[NT];   // weight fragments
+};
+
+template <bool BF16, int MT, int NT, int MODE>
 __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
   typedef Vec8<BF16> V;
   typedef typename V::elem T;
+  typedef Frag<BF16> F;
+  typedef typename F::raw raw_t;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, g = lane >> 4;
-  const int chunksN = (a.tilesN + NT - 1) / NT;
-  const int nblocks = gridDim.x;
-  const int logical = xcd_remap(blockIdx.x, nblocks);
-  const int mblk = logical / chunksN, nchunk = logical % chunksN;   // blocks sharing an A tile stay on one XCD
-  const int m0 = (mblk * 4 + wave) * (16 * MT);
-  const int ntile0 = nchunk * NT;
+  const int K = a.K, M = a.M;
   const T* A = reinterpret_cast<const T*>(a.A);
   const T* W = reinterpret_cast<const T*>(a.W);
-  const int K = a.K, M = a.M;
 
+  // ---- block / wave -> tile assignment ----
+  constexpr int TILES_PER_BLOCK_N = MODE == 1 ? 4 * NT : NT;
+  const int chunksN = (a.tilesN + TILES_PER_BLOCK_N - 1) / TILES_PER_BLOCK_N;
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);     // blocks sharing an A strip stay on one XCD
+  const int mblk = logical / chunksN, nchunk = logical % chunksN;
+  int m0, ntile0, kbeg = 0, kend = K;
+  if (MODE == 0) { m0 = (mblk * 4 + wave) * (16 * MT); ntile0 = nchunk * NT; }
+  else if (MODE == 1) { m0 = mblk * (16 * MT); ntile0 = nchunk * 4 * NT + wave * NT; }
+  else {
+    m0 = mblk * (16 * MT); ntile0 = nchunk * NT;
+    const int steps = (K + F::KSTEP - 1) / F::KSTEP, per = (steps + 3) / 4;
+    kbeg = min(K, wave * per * F::KSTEP); kend = min(K, (wave + 1) * per * F::KSTEP);
+  }
+
+  int mrow[MT]; bool mok[MT]; int mimg[MT];
+#pragma unroll
+  for (int i = 0; i < MT; i++) {
+    mrow[i] = m0 + i * 16 + r; mok[i] = mrow[i] < M;
+    mimg[i] = (a.se && mok[i]) ? mrow[i] / a.HW : 0;
+  }
   f32x4 acc[MT][NT];
 #pragma unroll
   for (int i = 0; i < MT; i++)
 #pragma unroll
     for (int j = 0; j < NT; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  int mrow[MT]; bool mok[MT]; int mimg[MT];
+  auto load = [&](Step<BF16, MT, NT>& st, int kk) {
+    const int k = kk + F::KLANE * g;
+    const bool kok = k < kend;
 #pragma unroll
-  for (int i = 0; i < MT; i++) {
-    mrow[i] = m0 + i * 16 + r; mok[i] = mrow[i] < M;
-    mimg[i] = a.se ? (mok[i] ? mrow[i] / a.HW : 0) : 0;
-  }
-
-  if constexpr (BF16) {
-    for (int kk = 0; kk < K; kk += 32) {
-      const int k = kk + 8 * g;
-      const bool kok = k < K;
+    for (int i = 0; i < MT; i++) {
+      raw_t v = {};
+      if (kok && mok[i]) v = *reinterpret_cast<const raw_t*>(A + (int64_t)mrow[i] * K + k);
+      st.a[i] = v;
+      if (a.se) {
+        f32x4 s0 = (f32x4){0.f, 0.f, 0.f, 0.f}, s1 = s0;
+        if (kok && mok[i]) {
+          const f32x4* sp = reinterpret_cast<const f32x4*>(a.se + (int64_t)mimg[i] * K + k);
+          s0 = sp[0];
+          if (BF16) s1 = sp[1];
+        }
+        st.s0[i] = s0; st.s1[i] = s1;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NT; j++) {
+      raw_t v = {};
+      if (kok && ntile0 + j < a.tilesN) v = *reinterpret_cast<const raw_t*>(W + (int64_t)((ntile0 + j) * 16 + r) * K + k);
+      st.w[j] = v;
+    }
+  };
+  auto compute = [&](Step<BF16, MT, NT>& st) {
+    if constexpr (BF16) {
       bf16x8 bfrag[MT];
 #pragma unroll
       for (int i = 0; i < MT; i++) {
-        u32x4 raw = (u32x4){0, 0, 0, 0};
-        if (kok && mok[i]) raw = *reinterpret_cast<const u32x4*>(A + (int64_t)mrow[i] * K + k);
-        if (a.se && kok && mok[i]) {
-          const f32x4* sp = reinterpret_cast<const f32x4*>(a.se + (int64_t)mimg[i] * K + k);
-          f32x4 s0 = sp[0], s1 = sp[1];
-          float s[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+        u32x4 raw = st.a[i];
+        if (a.se) {
+          const float s[8] = {st.s0[i][0], st.s0[i][1], st.s0[i][2], st.s0[i][3], st.s1[i][0], st.s1[i][1], st.s1[i][2], st.s1[i][3]};
 #pragma unroll
-          for (int q = 0; q < 4; q++) {
-            float lo = __uint_as_float(raw[q] << 16) * s[2 * q];
-            float hi = __uint_as_float(raw[q] & 0xffff0000u) * s[2 * q + 1];
-            raw[q] = pack_bf16x2(lo, hi);
-          }
+          for (int q = 0; q < 4; q++)
+            raw[q] = pack_bf16x2(__uint_as_float(raw[q] << 16) * s[2 * q], __uint_as_float(raw[q] & 0xffff0000u) * s[2 * q + 1]);
         }
         bfrag[i] = __builtin_bit_cast(bf16x8, raw);
       }
 #pragma unroll
       for (int j = 0; j < NT; j++) {
-        const int nt = ntile0 + j;
-        if (nt < a.tilesN) {
-          u32x4 raw = (u32x4){0, 0, 0, 0};
-          if (kok) raw = *reinterpret_cast<const u32x4*>(W + (int64_t)(nt * 16 + r) * K + k);
-          bf16x8 afrag = __builtin_bit_cast(bf16x8, raw);
+        const bf16x8 afrag = __builtin_bit_cast(bf16x8, st.w[j]);
 #pragma unroll
-          for (int i = 0; i < MT; i++)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag, bfrag[i], acc[i][j], 0, 0, 0);
-        }
+        for (int i = 0; i < MT; i++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag, bfrag[i], acc[i][j], 0, 0, 0);
       }
-    }
-  } else {
-    for (int kk = 0; kk < K; kk += 16) {
-      const int k = kk + 4 * g;
-      const bool kok = k < K;
-      f32x4 bfrag[MT];
+    } else {
 #pragma unroll
       for (int i = 0; i < MT; i++) {
-        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (kok && mok[i]) v = *reinterpret_cast<const f32x4*>(A + (int64_t)mrow[i] * K + k);
-        if (a.se && kok && mok[i]) v *= *reinterpret_cast<const f32x4*>(a.se + (int64_t)mimg[i] * K + k);
-        bfrag[i] = v;
-      }
+        f32x4 x = st.a[i];
+        if (a.se) x *= st.s0[i];
 #pragma unroll
-      for (int j = 0; j < NT; j++) {
-        const int nt = ntile0 + j;
-        if (nt < a.tilesN) {
-          f32x4 w = (f32x4){0.f, 0.f, 0.f, 0.f};
-          if (kok) w = *reinterpret_cast<const f32x4*>(W + (int64_t)(nt * 16 + r) * K + k);
+        for (int j = 0; j < NT; j++)
 #pragma unroll
-          for (int i = 0; i < MT; i++)
-#pragma unroll
-            for (int q = 0; q < 4; q++)   // lane group g supplies k = kk+4g+q to both operands
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[q], bfrag[i][q], acc[i][j], 0, 0, 0);
-        }
+          for (int q = 0; q < 4; q++)   // lane group g supplies k = kk+4g+q to both operands
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(st.w[j][q], x[q], acc[i][j], 0, 0, 0);
       }
     }
+  };
+
+  if (kbeg < kend) {
+    Step<BF16, MT, NT> cur, nxt;
+    load(cur, kbeg);
+    int kk = kbeg;
+    for (; kk + F::KSTEP < kend; kk += F::KSTEP) {
+      load(nxt, kk + F::KSTEP);
+      compute(cur);
+      cur = nxt;
+    }
+    compute(cur);
   }
 
-  // epilogue: lane holds n = nt*16 + 4g + {0..3} for pixel row m = ... + r
+  if (MODE == 2) {   // meet the four K-slices in LDS; wave w finishes n-tiles j = w, w+4, ...
+    __shared__ f32x4 red[4][NT][64];
+#pragma unroll
+    for (int j = 0; j < NT; j++) red[wave][j][lane] = acc[0][j];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NT; j++)
+      if ((j & 3) == wave) acc[0][j] = (red[0][j][lane] + red[1][j][lane]) + (red[2][j][lane] + red[3][j][lane]);
+  }
+
+  // ---- epilogue: lane holds n = nt*16 + 4g + {0..3} for pixel row m0 + 16 i + r ----
   const T* R = reinterpret_cast<const T*>(a.res);
 #pragma unroll
   for (int j = 0; j < NT; j++) {
+    if (MODE == 2 && (j & 3) != wave) continue;
     const int n = (ntile0 + j) * 16 + 4 * g;
     if (n >= a.N) continue;
     const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias + n);
@@ -133,19 +180,26 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
   }
 }
 
-template <bool BF16, int MT>
+template <bool BF16, int MT, int MODE>
 static void launch_nt(const PwArgs& a, dim3 grid, hipStream_t s) {
   switch (a.NT) {
-#define CASE(n) case n: hipLaunchKernelGGL((pw_gemm_kernel<BF16, MT, n>), grid, dim3(256), 0, s, a); break;
+#define CASE(n) case n: hipLaunchKernelGGL((pw_gemm_kernel<BF16, MT, n, MODE>), grid, dim3(256), 0, s, a); break;
     CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
 #undef CASE
   }
 }
 
+template <bool BF16>
+static void launch_t(const PwArgs& a, hipStream_t s) {
+  const int per_block_n = a.mode == 1 ? 4 * a.NT : a.NT;
+  const int chunksN = (a.tilesN + per_block_n - 1) / per_block_n;
+  const int rows = a.mode == 0 ? 64 * a.MT : 16;
+  dim3 grid(((a.M + rows - 1) / rows) * chunksN);
+  if (a.mode == 0) { if (a.MT == 2) launch_nt<BF16, 2, 0>(a, grid, s); else launch_nt<BF16, 1, 0>(a, grid, s); }
+  else if (a.mode == 1) launch_nt<BF16, 1, 1>(a, grid, s);
+  else launch_nt<BF16, 1, 2>(a, grid, s);
+}
+
 void launch_pw(const PwArgs& a, hipStream_t s) {
-  const int chunksN = (a.tilesN + a.NT - 1) / a.NT;
-  const int mblocks = (a.M + 64 * a.MT - 1) / (64 * a.MT);
-  dim3 grid(mblocks * chunksN);
-  if (a.bf16) { if (a.MT == 2) launch_nt<true, 2>(a, grid, s); else launch_nt<true, 1>(a, grid, s); }
-  else        { if (a.MT == 2) launch_nt<false, 2>(a, grid, s); else launch_nt<false, 1>(a, grid, s); }
+  if (a.bf16) launch_t<true>(a, s); else launch_t<false>(a, s);
 }

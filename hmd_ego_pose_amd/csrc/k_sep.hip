@@ -8,22 +8,34 @@
 // `conv(feat); bn(feat); swish(feat)` / the header conv + permute/view/cat
 // (efficientdet/model.py:361-417; hmdegopose/model.py:55-90,127-156,191-228).
 //
-// One workgroup = one 8x8 output tile of one image of one "segment" (a node, or one
-// (head, level) pair); a single launch covers every segment of a layer, e.g. all 5 heads x 5
-// levels of tower layer i.  The 10x10 halo of the fused map lives in LDS as fp32, the depthwise
-// result goes to LDS as the MFMA operand tile [64 pixels][C], and the 1x1 conv is the same
-// transposed MFMA product as k_pw.hip (W fragment = A operand, pixels = B operand) so each lane
-// ends with 4 consecutive output channels of one pixel.  Head outputs are written directly at
-// their anchor offset in the [B, N_anchors, K] result (no permute / cat pass).
+// One workgroup (8 waves) = one 8x8 output tile of one image of one "segment" (a node, or one
+// (head, level, column-chunk) triple); a single launch covers every segment of a layer, e.g. all
+// 5 heads x 5 levels of tower layer i.  These maps are tiny (32x32 .. 2x2 per image), so the
+// kernel is latency-bound: the design goal is the shortest dependent chain per workgroup.
+//   phase 0  issue the first pointwise-weight fragments (registers) and copy the depthwise
+//            weights + bias to LDS - nothing below depends on them until phase 3
+//   phase 1  fused (+swish) 10x10 halo of the depthwise input -> LDS fp32, zero outside the map
+//   phase 2  depthwise 3x3 from LDS -> MFMA operand tile [64 pixels][C] in LDS
+//   phase 3  1x1 conv as the transposed MFMA product of k_pw.hip (W fragment = A operand,
+//            pixels = B operand); (m-tile, n-tile) pairs are dealt round-robin to the 8 waves and
+//            the weight fragments run 4 deep ahead of the MFMAs in a register ring.
+// Head outputs are written directly at their anchor offset in the [B, N_anchors, K] result (no
+// permute / cat pass).
+#include <type_traits>
+
 #include "hep_dev.h"
 #include "hep_internal.h"
 
+#define SEP_THREADS 512
+#define SEP_WAVES 8
+
 __host__ __device__ static inline int sep_cp(int C) { return C + 4; }                 // halo row pitch (floats)
 __host__ __device__ static inline int sep_ca(int C, int bf16) { return bf16 ? C + 8 : C + 4; }
+__host__ __device__ static inline size_t sep_off_atile(int C) { return (size_t)100 * sep_cp(C) * 4; }
+__host__ __device__ static inline size_t sep_off_wdw(int C, int bf16) { return sep_off_atile(C) + (size_t)64 * sep_ca(C, bf16) * (bf16 ? 2 : 4); }
+__host__ __device__ static inline size_t sep_off_bias(int C, int bf16) { return sep_off_wdw(C, bf16) + (size_t)9 * C * 4; }
 
-size_t sep_lds_bytes(int C, int bf16) {
-  return (size_t)100 * sep_cp(C) * 4 + (size_t)64 * sep_ca(C, bf16) * (bf16 ? 2 : 4);
-}
+size_t sep_lds_bytes(int C, int bf16) { return sep_off_bias(C, bf16) + (size_t)SEP_MAX_TILES_N * 16 * 4; }
 
 template <bool BF16>
 __device__ __forceinline__ void gather_src(const SepSeg& sg, int i, int b, int y, int x, int c0, float v[8]) {
@@ -35,45 +47,77 @@ __device__ __forceinline__ void gather_src(const SepSeg& sg, int i, int b, int y
   } else if (sg.kind[i] == SRC_UP) {
     V::load(sg.src[i], img + ((int64_t)(y >> 1) * sw + (x >> 1)) * C + c0, v);
   } else {   // SRC_DOWN: 3x3/2 max-pool, zero padding takes part in the max
-    bool first = true;
+    // one row of the window (3 loads in flight) at a time keeps the register footprint small
 #pragma unroll
-    for (int ky = 0; ky < 3; ky++)
+    for (int ky = 0; ky < 3; ky++) {
+      float t[3][8];
 #pragma unroll
       for (int kx = 0; kx < 3; kx++) {
         const int iy = 2 * y - sg.pool_pad[i] + ky, ix = 2 * x - sg.pool_pad[i] + kx;
-        float t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (iy >= 0 && iy < sh && ix >= 0 && ix < sw) V::load(sg.src[i], img + ((int64_t)iy * sw + ix) * C + c0, t);
 #pragma unroll
-        for (int c = 0; c < 8; c++) v[c] = first ? t[c] : fmaxf(v[c], t[c]);
-        first = false;
+        for (int c = 0; c < 8; c++) t[kx][c] = 0.f;
+        if (iy >= 0 && iy < sh && ix >= 0 && ix < sw) V::load(sg.src[i], img + ((int64_t)iy * sw + ix) * C + c0, t[kx]);
       }
+#pragma unroll
+      for (int c = 0; c < 8; c++) {
+        const float m = fmaxf(fmaxf(t[0][c], t[1][c]), t[2][c]);
+        v[c] = ky == 0 ? m : fmaxf(v[c], m);
+      }
+    }
   }
 }
 
 template <bool BF16>
-__global__ __launch_bounds__(256) void sep_kernel(SepArgs a) {
+__global__ __launch_bounds__(SEP_THREADS, 4) void sep_kernel(SepArgs a) {
   typedef Vec8<BF16> V;
   typedef typename V::elem T;
+  typedef typename std::conditional<BF16, u32x4, f32x4>::type raw_t;
+  constexpr int KSTEP = BF16 ? 32 : 16, KLANE = BF16 ? 8 : 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // ---- locate the segment and tile ----
-  int si = 0;
-  for (int i = 1; i < a.nseg; i++) if ((int)blockIdx.x >= a.segs[i].tile_begin) si = i;
-  const SepSeg& sg = a.segs[si];
+  // one table lookup, then the whole descriptor by VALUE: it lands in scalar registers once, instead
+  // of being re-read from global memory (a dependent round trip) at every use after a barrier
+  const SepSeg sg = a.segs[a.tile_seg[blockIdx.x]];
   const int C = sg.C, CG = C >> 3, h = sg.h, w = sg.w;
-  const int local = blockIdx.x - sg.tile_begin;
-  const int b = blockIdx.y, t = local;     // grid = (tiles of one image over all segments, batch)
+  const int t = blockIdx.x - sg.tile_begin;
+  const int b = blockIdx.y;                 // grid = (tiles of one image over all segments, batch)
   const int y0 = (t / sg.tiles_x) * 8, x0 = (t % sg.tiles_x) * 8;
   const int CP = sep_cp(C), CA = sep_ca(C, BF16);
   float* halo = reinterpret_cast<float*>(smem);
-  T* atile = reinterpret_cast<T*>(smem + (size_t)100 * CP * 4);
+  T* atile = reinterpret_cast<T*>(smem + sep_off_atile(C));
+  float* wdw_s = reinterpret_cast<float*>(smem + sep_off_wdw(C, BF16));
+  float* bias_s = reinterpret_cast<float*>(smem + sep_off_bias(C, BF16));
+
+  // ---- phase 0: weight prefetch (independent of the activations) ----
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int rows_valid = min(8, h - y0);
+  const int mtv = (rows_valid + 1) >> 1;                // m-tiles (2 tile rows = 16 pixels) with any valid pixel
+  const int ksteps = (C + KSTEP - 1) / KSTEP;
+  const int nitems = mtv * sg.tilesN * ksteps;          // (pair, kstep) items; pair = nt * mtv + mt
+  const T* W = reinterpret_cast<const T*>(sg.wpw);
+  auto wload = [&](int it) -> raw_t {                   // it = this wave's it-th (pair, kstep)
+    raw_t v = {};
+    const int pair = wave + SEP_WAVES * (it / ksteps), ks = it % ksteps;
+    const int k = ks * KSTEP + KLANE * g;
+    if (pair < mtv * sg.tilesN && k < C) v = *reinterpret_cast<const raw_t*>(W + (int64_t)((pair / mtv) * 16 + r) * C + k);
+    return v;
+  };
+  raw_t wring[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) wring[q] = wload(q);
+  for (int i = threadIdx.x; i < 9 * C; i += SEP_THREADS) wdw_s[i] = sg.wdw[i];
+  for (int i = threadIdx.x; i < sg.tilesN * 16; i += SEP_THREADS) bias_s[i] = sg.bias[i];
 
   // ---- phase 1: fused (+swish) 10x10 halo of the depthwise input, zero outside the image ----
-  for (int item = threadIdx.x; item < 100 * CG; item += 256) {
+  for (int item = threadIdx.x; item < 100 * CG; item += SEP_THREADS) {
     const int pos = item / CG, cg = item % CG;
     const int y = y0 + pos / 10 - 1, x = x0 + pos % 10 - 1;
     float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (y >= 0 && y < h && x >= 0 && x < w) {
-      for (int i = 0; i < sg.nsrc; i++) {
+#pragma unroll
+      for (int i = 0; i < HEP_MAX_SRC; i++) {
+        if (i >= sg.nsrc) break;
         float s[8];
         gather_src<BF16>(sg, i, b, y, x, cg * 8, s);
 #pragma unroll
@@ -91,7 +135,7 @@ __global__ __launch_bounds__(256) void sep_kernel(SepArgs a) {
   __syncthreads();
 
   // ---- phase 2: depthwise 3x3 -> operand tile [64 pixels][C] ----
-  for (int item = threadIdx.x; item < 64 * CG; item += 256) {
+  for (int item = threadIdx.x; item < 64 * CG; item += SEP_THREADS) {
     const int p = item / CG, cg = item % CG;
     const int py = p >> 3, px = p & 7;
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -100,7 +144,7 @@ __global__ __launch_bounds__(256) void sep_kernel(SepArgs a) {
 #pragma unroll
       for (int kx = 0; kx < 3; kx++) {
         const f32x4* hp = reinterpret_cast<const f32x4*>(halo + ((py + ky) * 10 + px + kx) * CP + cg * 8);
-        const f32x4* wp = reinterpret_cast<const f32x4*>(sg.wdw + (ky * 3 + kx) * C + cg * 8);
+        const f32x4* wp = reinterpret_cast<const f32x4*>(wdw_s + (ky * 3 + kx) * C + cg * 8);
         const f32x4 h0 = hp[0], h1 = hp[1], w0 = wp[0], w1 = wp[1];
 #pragma unroll
         for (int c = 0; c < 4; c++) { acc[c] = fmaf(h0[c], w0[c], acc[c]); acc[4 + c] = fmaf(h1[c], w1[c], acc[4 + c]); }
@@ -110,55 +154,57 @@ __global__ __launch_bounds__(256) void sep_kernel(SepArgs a) {
   __syncthreads();
 
   // ---- phase 3: pointwise conv, D[n, pixel] = W[n,:] . tile[pixel,:] ----
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int r = lane & 15, g = lane >> 4;
-  if (y0 + 2 * wave >= h) return;                      // this wave's two tile rows are outside the map
-  const int m = wave * 16 + r;
-  const int y = y0 + (m >> 3), x = x0 + (m & 7);
-  const bool pix_ok = y < h && x < w;
-  const T* W = reinterpret_cast<const T*>(sg.wpw);
-  const int64_t obase = (int64_t)b * sg.out_bstride + sg.out_off + ((int64_t)y * w + x) * sg.out_rowstride;
-  for (int nt = 0; nt < sg.tilesN; nt++) {
-    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int my_pairs = (mtv * sg.tilesN - wave + SEP_WAVES - 1) / SEP_WAVES;    // pairs wave, wave+8, ...
+  if (my_pairs <= 0) return;
+  const int my_items = my_pairs * ksteps;
+  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+  auto step = [&](int it, raw_t wfrag) {
+    const int pair = wave + SEP_WAVES * (it / ksteps), ks = it % ksteps;
+    const int mt = pair % mtv, nt = pair / mtv;
+    const int m = mt * 16 + r;
+    const int k = ks * KSTEP + KLANE * g;
+    raw_t xa = {};
+    if (k < C) xa = *reinterpret_cast<const raw_t*>(atile + (int64_t)m * CA + k);
     if constexpr (BF16) {
-      for (int kk = 0; kk < C; kk += 32) {
-        const int k = kk + 8 * g;
-        u32x4 wa = (u32x4){0, 0, 0, 0}, xa = (u32x4){0, 0, 0, 0};
-        if (k < C) {
-          wa = *reinterpret_cast<const u32x4*>(W + (int64_t)(nt * 16 + r) * C + k);
-          xa = *reinterpret_cast<const u32x4*>(atile + (int64_t)m * CA + k);
-        }
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wa), __builtin_bit_cast(bf16x8, xa), acc, 0, 0, 0);
-      }
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wfrag), __builtin_bit_cast(bf16x8, xa), acc, 0, 0, 0);
     } else {
-      for (int kk = 0; kk < C; kk += 16) {
-        const int k = kk + 4 * g;
-        f32x4 wa = (f32x4){0.f, 0.f, 0.f, 0.f}, xa = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (k < C) {
-          wa = *reinterpret_cast<const f32x4*>(W + (int64_t)(nt * 16 + r) * C + k);
-          xa = *reinterpret_cast<const f32x4*>(atile + (int64_t)m * CA + k);
-        }
 #pragma unroll
-        for (int q = 0; q < 4; q++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[q], xa[q], acc, 0, 0, 0);
+      for (int q = 0; q < 4; q++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wfrag[q], xa[q], acc, 0, 0, 0);
+    }
+    if (ks != ksteps - 1) return;
+    // ---- epilogue of this (m-tile, n-tile) pair ----
+    const int y = y0 + (m >> 3), x = x0 + (m & 7);
+    const int n = nt * 16 + 4 * g;
+    if (y < h && x < w && n < sg.N) {
+      const f32x4 bias = *reinterpret_cast<const f32x4*>(bias_s + n);
+      float v[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) v[q] = apply_act(acc[q] + bias[q], sg.act);
+      const int64_t obase = (int64_t)b * sg.out_bstride + sg.out_off + ((int64_t)y * w + x) * sg.out_rowstride;
+      if (sg.out_f32) {
+        float* o = reinterpret_cast<float*>(sg.out) + obase;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int nn = n + q + sg.n_base;
+          if (n + q < sg.N) o[(nn / sg.col_kin) * sg.col_kout + nn % sg.col_kin + sg.col_off] = v[q];
+        }
+      } else {
+        V::store4(sg.out, obase + n, v);     // N is a multiple of 8 for every non-header layer
       }
     }
-    const int n = nt * 16 + 4 * g;
-    if (!pix_ok || n >= sg.N) continue;
-    const f32x4 bias = *reinterpret_cast<const f32x4*>(sg.bias + n);
-    float v[4];
+    acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+  };
+  for (int it = 0; it < my_items; it += 4) {
 #pragma unroll
-    for (int q = 0; q < 4; q++) v[q] = apply_act(acc[q] + bias[q], sg.act);
-    if (sg.out_f32) {
-      float* o = reinterpret_cast<float*>(sg.out) + obase;
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const int nn = n + q;
-        if (nn < sg.N) o[(nn / sg.col_kin) * sg.col_kout + nn % sg.col_kin + sg.col_off] = v[q];
+    for (int q = 0; q < 4; q++) {
+      if (it + q < my_items) {
+        const raw_t wf = wring[q];
+        wring[q] = wload(it + q + 4);       // refill the slot 4 items ahead (zero past the end)
+        step(it + q, wf);
       }
-    } else {
-      V::store4(sg.out, obase + n, v);     // N is a multiple of 8 for every non-header layer
     }
   }
+  (void)nitems;
 }
 
 int sep_prepare(void) {
@@ -171,6 +217,6 @@ int sep_prepare(void) {
 
 void launch_sep(const SepArgs& a, hipStream_t s) {
   dim3 grid(a.total_tiles, a.B);
-  if (a.bf16) hipLaunchKernelGGL(sep_kernel<true>, grid, dim3(256), a.lds_bytes, s, a);
-  else hipLaunchKernelGGL(sep_kernel<false>, grid, dim3(256), a.lds_bytes, s, a);
+  if (a.bf16) hipLaunchKernelGGL(sep_kernel<true>, grid, dim3(SEP_THREADS), a.lds_bytes, s, a);
+  else hipLaunchKernelGGL(sep_kernel<false>, grid, dim3(SEP_THREADS), a.lds_bytes, s, a);
 }

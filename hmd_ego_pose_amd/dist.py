@@ -1,0 +1,123 @@
+"""Multi-GPU sharding of frame batches: one process per GPU, ``torch.distributed``
+(backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).
+
+Frames are independent in eval mode (no cross-sample op anywhere on the path), so the
+forward itself needs NO collective: every rank holds a full copy of the weights and runs
+its own contiguous slice of the global batch (weak scaling).  Collectives appear only at
+the edges of a serving job and are kept off the per-frame critical path:
+
+  * ``broadcast_state_dict``  one-time weight broadcast from rank 0 (8.7 MB bf16 for phi 0),
+  * ``scatter_frames``        optional: rank 0 holds the global batch and deals slices
+                              (point-to-point sends: xGMI gives rank 0 a direct link to each peer),
+  * ``gather_detections``     post-filter rows only (<=100 x 75 floats per frame, 30 KB) - never
+                              the raw heads (3.6 MB per frame), SURVEY.md section 8e.
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def env_world() -> Tuple[int, int, int]:
+    """(rank, local_rank, world_size) from the torchrun environment (1 process = 1 GPU)."""
+    return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+
+
+def shard_range(global_batch: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous slice [lo, hi) of the global batch owned by ``rank``; the first
+    ``global_batch % world`` ranks take one extra frame."""
+    if world < 1 or not 0 <= rank < world:
+        raise ValueError("bad rank/world")
+    base, extra = divmod(global_batch, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def init(backend: Optional[str] = None) -> Tuple[int, int, int]:
+    rank, local_rank, world = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        be = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        if be == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(be, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def broadcast_state_dict(state: Dict[str, torch.Tensor], device: torch.device, src: int = 0) -> Dict[str, torch.Tensor]:
+    """One flat broadcast of every float tensor (one large message instead of ~900 small ones)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return state
+    keys = [k for k, v in state.items() if torch.is_floating_point(v)]
+    flat = torch.cat([state[k].reshape(-1).float() for k in keys]).to(device)
+    dist.broadcast(flat, src)
+    out, off = dict(state), 0
+    for k in keys:
+        n = state[k].numel()
+        out[k] = flat[off:off + n].reshape(state[k].shape).to(state[k].device)
+        off += n
+    return out
+
+
+def scatter_frames(global_frames: Optional[torch.Tensor], global_batch: int, shape: Tuple[int, ...], device: torch.device,
+                   src: int = 0) -> torch.Tensor:
+    """Rank ``src`` holds [global_batch, *shape]; every rank returns its slice."""
+    rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
+    lo, hi = shard_range(global_batch, rank, world)
+    if world == 1:
+        return global_frames[lo:hi].to(device)
+    mine = torch.empty((hi - lo, *shape), dtype=torch.float32, device=device)
+    if rank == src:
+        reqs = []
+        for r in range(world):
+            l, h = shard_range(global_batch, r, world)
+            if r == src:
+                mine.copy_(global_frames[l:h])
+            elif h > l:
+                reqs.append(dist.isend(global_frames[l:h].contiguous().to(device), r))
+        for q in reqs:
+            q.wait()
+    elif hi > lo:
+        dist.recv(mine, src)
+    return mine
+
+
+def gather_detections(det: Dict[str, torch.Tensor], global_batch: int, dst: int = 0) -> Optional[Dict[str, torch.Tensor]]:
+    """Gather the per-frame detection rows of every rank on ``dst`` in global frame order."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return det
+    rank, world = dist.get_rank(), dist.get_world_size()
+    out: Dict[str, torch.Tensor] = {}
+    for k in sorted(det):
+        t = det[k].contiguous()
+        if rank == dst:
+            parts: List[torch.Tensor] = []
+            for r in range(world):
+                l, h = shard_range(global_batch, r, world)
+                if r == dst:
+                    parts.append(t)
+                elif h > l:
+                    buf = torch.empty((h - l, *t.shape[1:]), dtype=t.dtype, device=t.device)
+                    dist.recv(buf, r)
+                    parts.append(buf)
+            out[k] = torch.cat(parts, 0)
+        elif t.shape[0] > 0:
+            dist.send(t, dst)
+    return out if rank == dst else None
+
+
+def max_over_ranks(seconds: float, device: torch.device) -> float:
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return seconds
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def barrier():
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()

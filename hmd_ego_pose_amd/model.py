@@ -122,13 +122,16 @@ class Session:
                 return out
         raise KeyError(name)
 
-    def kernels(self, batch: int) -> List[Tuple[str, float, float]]:
+    def kernels(self, batch: int) -> List[Tuple[str, float, float, str]]:
+        """(launch name, algorithmic bytes, flops, device function) of every launch in one forward."""
         l = _capi.lib()
         out = []
         for i in range(l.hep_kernel_count(self.handle, batch)):
             nm = ctypes.c_char_p(); b = ctypes.c_double(); f = ctypes.c_double()
             _capi.check(l.hep_kernel_info(self.handle, batch, i, ctypes.byref(nm), ctypes.byref(b), ctypes.byref(f)))
-            out.append((nm.value.decode(), b.value, f.value))
+            sym = ctypes.c_char_p()
+            _capi.check(l.hep_kernel_symbol(self.handle, i, ctypes.byref(sym)))
+            out.append((nm.value.decode(), b.value, f.value, sym.value.decode()))
         return out
 
     def profile(self, batch: int, iters: int = 20, per_kernel: bool = False):

@@ -136,8 +136,11 @@ int hep_debug_tensor(hep_handle* h, const char* name, int batch, float* out, siz
 int hep_kernel_count(const hep_handle* h, int batch);      /* launches in one forward                      */
 /* Per-launch description of the forward plan: name, algorithmic bytes and flops for `batch`. */
 int hep_kernel_info(const hep_handle* h, int batch, int i, const char** name, double* bytes, double* flops);
+/* Device function (as rocprofv3 --kernel-trace names it, e.g. "sep_kernel<true>") behind launch i. */
+int hep_kernel_symbol(const hep_handle* h, int i, const char** symbol);
 /* Time `iters` replays of the forward at `batch` with HIP events on the handle's own stream; when
- * per_kernel_ms is non-NULL (length hep_kernel_count) also time every launch eagerly, one by one. */
+ * per_kernel_ms is non-NULL (length hep_kernel_count) also run the forward eagerly with a HIP event
+ * in front of every launch and return each launch's average in-sequence duration. */
 int hep_profile(hep_handle* h, int batch, int iters, float* total_ms_per_iter, float* per_kernel_ms);
 
 #ifdef __cplusplus

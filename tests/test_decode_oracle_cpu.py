@@ -1,0 +1,103 @@
+"""CPU: the numpy decode oracle on hand-built known-answer cases (NMS, padding, post-filter,
+ADD / ADD-S), i.e. the parts of the path whose reference implementation (TensorFlow, OpenCV,
+Cython) cannot run here.  The expected answers are derived by hand from the rule stated in
+oracle/decode_ref.py (greedy, IoU strictly greater than the threshold suppresses, ties by
+lower index)."""
+import math
+
+import numpy as np
+
+from oracle import decode_ref as D
+
+
+def _boxes():
+    # 3 clusters; scores chosen so the expected survivors are obvious
+    b = np.array([
+        [10, 10, 50, 50],      # 0  s=.90  keep (best of cluster A)
+        [12, 12, 52, 52],      # 1  s=.80  IoU with 0 = 0.82 -> suppressed
+        [10, 10, 50, 90],      # 2  s=.70  IoU with 0 = 0.5 exactly -> NOT suppressed (strict >)
+        [100, 100, 140, 140],  # 3  s=.95  keep (global best)
+        [101, 101, 141, 141],  # 4  s=.95  tie with 3 -> index 3 first, 4 suppressed (IoU .905)
+        [200, 200, 220, 220],  # 5  s=.40  below threshold
+        [300, 300, 300, 340],  # 6  s=.99  degenerate (zero area): IoU 0 with everything -> kept
+        [300, 300, 300, 340],  # 7  s=.60  identical degenerate box: IoU 0 -> kept too
+    ], dtype=np.float32)
+    s = np.array([.90, .80, .70, .95, .95, .40, .99, .60], dtype=np.float32)
+    return b, s
+
+
+def test_iou_known_values():
+    b, _ = _boxes()
+    assert abs(float(D.iou_xyxy(b[0], b[2])) - 0.5) < 1e-7
+    assert abs(float(D.iou_xyxy(b[0], b[1])) - (38 * 38) / (2 * 1600 - 38 * 38)) < 1e-6
+    assert float(D.iou_xyxy(b[6], b[7])) == 0.0
+    # coordinate-order invariance: the reference passes (x1,y1,x2,y2) to a (y1,x1,y2,x2) API
+    sw = lambda v: v[[1, 0, 3, 2]]
+    assert D.iou_xyxy(sw(b[0]), sw(b[1])) == D.iou_xyxy(b[0], b[1])
+
+
+def test_nms_known_answer_and_padding():
+    b, s = _boxes()
+    n = len(s)
+    rot = np.arange(n * 3, dtype=np.float32).reshape(n, 3)
+    tr = -np.arange(n * 3, dtype=np.float32).reshape(n, 3)
+    hand = np.tile(np.arange(n, dtype=np.float32)[:, None], (1, 63))
+    out = D.filter_detections(b, s[:, None], rot, tr, hand, score_threshold=0.5, max_detections=6, nms_threshold=0.5)
+    boxes, scores, labels, r, t, h, idx = out
+    assert idx.tolist() == [6, 3, 0, 2, 7, -1]
+    assert scores[:5].tolist() == [s[6], s[3], s[0], s[2], s[7]] and scores[5] == -1
+    assert labels.tolist() == [0, 0, 0, 0, 0, -1] and labels.dtype == np.int32
+    assert np.array_equal(boxes[1], b[3]) and np.all(boxes[5] == -1) and np.all(h[5] == -1) and np.all(r[5] == -1)
+    assert np.array_equal(r[2], rot[0]) and np.array_equal(t[3], tr[2]) and h[4, 0] == 7
+    # max_detections caps the greedy pass itself (max_output_size)
+    out2 = D.filter_detections(b, s[:, None], rot, tr, hand, score_threshold=0.5, max_detections=2, nms_threshold=0.5)
+    assert out2[6].tolist() == [6, 3]
+    # nothing above threshold -> all padding
+    out3 = D.filter_detections(b, s[:, None] * 0, rot, tr, hand, max_detections=3)
+    assert out3[6].tolist() == [-1, -1, -1] and np.all(out3[0] == -1)
+
+
+def test_post_filter_matches_evaluate_loop():
+    b, s = _boxes()
+    rot = np.ones((8, 3), np.float32) * 0.5
+    tr = np.ones((8, 3), np.float32)
+    bx, sc, r, t = D.post_filter(b, s, rot, tr, scale=0.8, score_threshold=0.75, max_detections=3)
+    assert sc.tolist() == [s[6], s[3], s[4]]            # stable sort keeps 3 before 4
+    assert np.allclose(bx[1], b[3] / 0.8) and np.allclose(r, 0.5 * math.pi)
+
+
+def test_add_and_add_s_on_synthetic_poses():
+    rng = np.random.Generator(np.random.PCG64(7))
+    pts = rng.uniform(-100, 100, (2500, 3))
+    diameter = 380.031          # datasets/syn_colibri/models/models_info.yml:1
+    R = D.rodrigues(np.array([0.1, -0.2, 0.3]))
+    assert np.allclose(R @ R.T, np.eye(3), atol=1e-12) and abs(np.linalg.det(R) - 1) < 1e-12
+    t = np.array([10.0, -5.0, 500.0])
+    ok, d = D.add_metric(pts, diameter, R, t, R, t + np.array([3.0, 4.0, 0.0]))
+    assert ok and abs(d - 5.0) < 1e-9                   # pure translation error = |dt| for every point
+    ok, d = D.add_metric(pts, diameter, R, t, R, t + np.array([30.0, 40.0, 0.0]))
+    assert (not ok) and abs(d - 50.0) < 1e-9            # 50 > 0.1 * 380.031
+    # ADD-S: subsampling step = 2500//1000+1 = 3 -> 834 points; identical pose -> 0
+    ok, d = D.add_s_metric(pts, diameter, R, t, R, t)
+    assert ok and d == 0.0
+    # ADD-S <= ADD always (nearest neighbour instead of corresponding point)
+    R2 = D.rodrigues(np.array([0.1, -0.2, 0.35]))
+    _, dadd = D.add_metric(pts[::3], diameter, R, t, R2, t)
+    _, dadds = D.add_s_metric(pts, diameter, R, t, R2, t)
+    assert 0 < dadds <= dadd + 1e-6
+    # rodrigues known answer: 90 degrees about z
+    Rz = D.rodrigues(np.array([0, 0, math.pi / 2]))
+    assert np.allclose(Rz, [[0, -1, 0], [1, 0, 0], [0, 0, 1]], atol=1e-12)
+
+
+def test_decode_boxes_properties():
+    a, ta = D.anchors_for_size(256)
+    z = np.zeros((1, a.shape[0], 4), np.float32)
+    # zero deltas reproduce the (clipped) anchors
+    assert np.allclose(D.decode_boxes(a, z, 256)[0], np.clip(a, 0, 255), rtol=0, atol=1e-4)   # centre/size round trip
+    # translation: zero offsets at the principal point give Tx=Ty=0
+    cam = np.array([[480, 480, 132, 132, 1000, 1.0]], np.float32)     # (16+0.5)*8 = 132 is a P3 cell centre
+    raw = np.zeros((1, a.shape[0], 3), np.float32); raw[..., 2] = 0.5
+    tr = D.decode_translation(ta, raw, cam)[0]
+    centre = np.nonzero((ta[:, 0] == 132) & (ta[:, 1] == 132))[0]
+    assert len(centre) > 0 and np.all(tr[centre, :2] == 0) and np.all(tr[:, 2] == 500)

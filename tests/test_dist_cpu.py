@@ -1,0 +1,75 @@
+"""CPU, world_size 2 over gloo: the N>1 plumbing of the path - contiguous frame sharding,
+the one-time weight broadcast, frame scatter and detection gather (hmd_ego_pose_amd/dist.py).
+The forward itself needs no collective (frames are independent), so this is the whole
+multi-GPU surface; on the GPU box the same code runs over RCCL (backend "nccl")."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from hmd_ego_pose_amd.dist import broadcast_state_dict, gather_detections, max_over_ranks, scatter_frames, shard_range
+
+
+def test_shard_range_covers_batch_contiguously():
+    for g in (1, 7, 16, 128, 130):
+        for w in (1, 2, 3, 8):
+            spans = [shard_range(g, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == g
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [h - l for l, h in spans]
+            assert max(sizes) - min(sizes) <= 1
+    assert shard_range(128, 3, 8) == (48, 64)
+    with pytest.raises(ValueError):
+        shard_range(8, 2, 2)
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cpu")
+    try:
+        # weights: rank 0's values must arrive everywhere
+        state = {"a.weight": torch.full((3, 4), float(rank + 1)), "b.num_batches_tracked": torch.tensor(rank), "c.bias": torch.arange(5.) * (rank + 1)}
+        out = broadcast_state_dict(state, dev)
+        assert torch.equal(out["a.weight"], torch.ones(3, 4)) and torch.equal(out["c.bias"], torch.arange(5.))
+        assert out["b.num_batches_tracked"].item() == rank          # non-float entries stay local
+        # frames: global batch 5 on 2 ranks -> 3 + 2
+        G = 5
+        frames = torch.arange(G * 6, dtype=torch.float32).reshape(G, 1, 2, 3) if rank == 0 else None
+        mine = scatter_frames(frames, G, (1, 2, 3), dev)
+        lo, hi = shard_range(G, rank, world)
+        assert mine.shape[0] == hi - lo and torch.equal(mine, torch.arange(G * 6, dtype=torch.float32).reshape(G, 1, 2, 3)[lo:hi])
+        # "forward": per-frame result depends only on the frame -> gather restores global order
+        det = {"scores": mine.sum(dim=(1, 2, 3)), "index": torch.arange(lo, hi, dtype=torch.int32)}
+        got = gather_detections(det, G)
+        if rank == 0:
+            assert torch.equal(got["index"], torch.arange(G, dtype=torch.int32))
+            assert torch.equal(got["scores"], torch.arange(G * 6, dtype=torch.float32).reshape(G, -1).sum(1))
+        else:
+            assert got is None
+        assert max_over_ranks(float(rank + 1), dev) == float(world)
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        q.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_roundtrip():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=120) for _ in ps]
+    for p in ps:
+        p.join(60)
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res

@@ -1,0 +1,110 @@
+"""CPU (no GPU): host logic of the product - architecture tables, weight pack, the C-ABI
+library's exports and its host-only entry points, the nn.Module drop-in's state_dict
+contract and its loud refusal to run without a ROCm device."""
+import ctypes
+import hashlib
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from hmd_ego_pose_amd import _capi
+from hmd_ego_pose_amd.arch import get_arch, level_sizes, num_anchors_total, param_spec, same_pad
+from hmd_ego_pose_amd.weights import load_pack, pack_bytes, seeded_state_dict, strip_checkpoint_prefix
+from tests._util import golden_meta
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("phi", [0, 3])
+def test_param_spec_matches_reference_state_dict(phi):
+    spec = param_spec(phi)
+    assert hashlib.sha256(repr(spec).encode()).hexdigest() == golden_meta()[f"keys_phi{phi}_sha256"]
+    assert len(spec) == {0: 1048, 3: 1618}[phi]
+
+
+def test_arch_tables_phi0_phi3():
+    a = get_arch(0)
+    assert (a.stem, len(a.blocks), a.taps, a.tap_channels) == (32, 16, (4, 10, 15), (40, 112, 320))
+    assert [(b.cexp, b.k, b.stride) for b in a.blocks[:4]] == [(32, 3, 1), (96, 3, 2), (144, 3, 1), (144, 5, 2)]
+    assert [b.skip for b in a.blocks] == [False, False, True, False, True, False, True, True, False, True, True, False, True, True, True, False]
+    b = get_arch(3)
+    assert (b.stem, len(b.blocks), b.taps, b.tap_channels, b.fpn_w, b.fpn_cells, b.head_depth) == (40, 26, (7, 17, 25), (48, 136, 384), 160, 6, 4)
+    assert level_sizes(256) == [32, 16, 8, 4, 2] and num_anchors_total(256) == 12276 and num_anchors_total(512) == 49104
+    # TF-SAME asymmetry
+    assert same_pad(256, 3, 2) == (0, 1) and same_pad(64, 5, 2) == (1, 2) and same_pad(32, 3, 1) == (1, 1) and same_pad(16, 5, 1) == (2, 2)
+    with pytest.raises(ValueError):
+        get_arch(8)
+
+
+def test_weight_pack_roundtrip_and_prefixes():
+    sd = seeded_state_dict(0, 3)
+    blob = pack_bytes({("model.module." + k): v for k, v in sd.items()})
+    back = load_pack(blob)
+    assert "bifpn.0.p6_w1" in back and not any(k.endswith("num_batches_tracked") for k in back)
+    for k in ("backbone_net.model._conv_stem.conv.weight", "hand_net.initial_hand_coords.pointwise_conv.conv.bias"):
+        assert np.array_equal(back[k], sd[k].numpy())
+    assert list(strip_checkpoint_prefix({"model.bifpn.0.p6_w1": 1, "backbone_net.model._bn0.weight": 2})) == ["bifpn.0.p6_w1", "backbone_net.model._bn0.weight"]
+    # version-stable: same seed -> same bytes, different seed -> different
+    assert torch.equal(seeded_state_dict(0, 3)["regressor.header.pointwise_conv.conv.weight"], sd["regressor.header.pointwise_conv.conv.weight"])
+    assert not torch.equal(seeded_state_dict(0, 4)["bifpn.1.p4_w2"], sd["bifpn.1.p4_w2"])
+
+
+def test_library_exports_every_symbol_in_header():
+    """The C-ABI library loads and exports exactly what include/hep.h declares."""
+    header = open(os.path.join(REPO, "include", "hep.h")).read()
+    declared = set(re.findall(r"\b(hep_[a-z_0-9]+)\s*\(", header)) - {"hep_handle"}
+    assert declared == set(_capi.SYMBOLS), declared ^ set(_capi.SYMBOLS)
+    l = _capi.lib()
+    for name in declared:
+        assert hasattr(l, name), name
+    assert l.hep_abi_version() == 1
+
+
+@pytest.mark.parametrize("size", [256, 512])
+def test_hep_anchors_bit_exact_against_reference_fixtures(size):
+    """hep_anchors is host code (float64 math, one cast): bit-identical to the reference's
+    anchors_for_shape and to its onnx-models/*.txt fixtures."""
+    l = _capi.lib()
+    n = num_anchors_total(size)
+    a = np.empty((n, 4), np.float32); t = np.empty((n, 3), np.float32)
+    assert l.hep_anchors(size, a.ctypes.data, t.ctypes.data) == n
+    meta = golden_meta()
+    assert hashlib.sha256(a.tobytes()).hexdigest() == meta[f"anchors_{size}_sha256"]
+    assert hashlib.sha256(t.tobytes()).hexdigest() == meta[f"translation_anchors_{size}_sha256"]
+    assert l.hep_anchors(100, None, None) < 0 and b"multiple of 128" in l.hep_last_error()
+
+
+def test_create_fails_loudly_without_gpu_or_with_bad_pack():
+    l = _capi.lib()
+    h = ctypes.c_void_p()
+    rc = l.hep_create(b"/nonexistent/pack.hepw", 0, 256, 1, 0, 0, 0, ctypes.byref(h))
+    assert rc == -2 and b"cannot open" in l.hep_last_error() and not h.value
+    blob = pack_bytes(seeded_state_dict(0, 0))
+    if l.hep_device_count() == 0:     # this container: no silent CPU path
+        rc = l.hep_create_from_memory(blob, len(blob), 0, 256, 1, 0, 0, 0, ctypes.byref(h))
+        assert rc == -3 and b"no CPU fallback" in l.hep_last_error()
+    assert l.hep_create_from_memory(b"XXXX" + bytes(60), 64, 0, 256, 1, 0, 0, 0, ctypes.byref(h)) in (-2, -3)
+    assert l.hep_create_from_memory(blob, len(blob), 9, 256, 1, 0, 0, 0, ctypes.byref(h)) == -4
+    assert l.hep_create_from_memory(blob, len(blob), 0, 200, 1, 0, 0, 0, ctypes.byref(h)) == -4
+
+
+def test_module_state_dict_contract_and_cpu_refusal():
+    from hmd_ego_pose_amd import HMDEgoPose
+    m = HMDEgoPose({"iter": 0}, num_classes=1, compound_coef=0, onnx_export=True, input_sizes=[256] * 9)
+    assert [(k, tuple(v.shape)) for k, v in m.state_dict().items()] == param_spec(0)
+    sd = seeded_state_dict(0, 5)
+    res = m.load_state_dict({"model." + k: v for k, v in sd.items()}, strict=False)   # prefixed keys are NOT auto-stripped by torch
+    assert len(res.unexpected_keys) == len(sd)
+    assert m.load_state_dict(strip_checkpoint_prefix({"model." + k: v for k, v in sd.items()}), strict=True).missing_keys == []
+    assert torch.equal(m.state_dict()["rotation_net.initial_rotation.pointwise_conv.conv.bias"], sd["rotation_net.initial_rotation.pointwise_conv.conv.bias"])
+    m.eval()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(1, 3, 256, 256))
+    m.train()
+    with pytest.raises(RuntimeError, match="inference path"):
+        m(torch.zeros(1, 3, 256, 256))
+    with pytest.raises(ValueError, match="iter"):
+        HMDEgoPose({"iter": 1}, compound_coef=0)
