@@ -6,7 +6,7 @@
 #include <stdint.h>
 
 #define HEP_MAX_SRC 3
-#define SEP_MAX_TILES_N 12   // n-tiles (16 columns) per sepconv segment; wider layers are split into segments
+#define SEP_MAX_TILES_N 6    // n-tiles (16 columns) per sepconv segment; wider layers are split into segments
 
 enum { ACT_NONE = 0, ACT_SWISH = 1, ACT_SIGMOID = 2 };
 enum { SRC_SAME = 1, SRC_UP = 2, SRC_DOWN = 3 };   // gather kinds of a BiFPN fusion input
@@ -65,11 +65,14 @@ struct SepSeg {
   int64_t out_bstride, out_off, out_rowstride;   // elements: per image, level offset, per pixel
   int col_kin, col_kout, col_off;          // column nn = n_base + n -> (nn/kin)*kout + nn%kin + off
   int n_base;                              // first output column of this segment (wide headers are split)
-  int tiles_x, tiles_y, tile_begin;        // 8x8 tiles; tile_begin = prefix over segments (incl. batch)
+  int ts;                                  // tile side: 16 on maps >= 16x16 (bf16), else 8
+  int tiles_x, tiles_y, tile_begin;        // tile_begin = prefix of tiles-per-image over the launch's segments
 };
 struct SepArgs {
   const SepSeg* segs; const int* tile_seg;   // device tables: segments, and tile (blockIdx.x) -> segment
-  int nseg; int B; int total_tiles; int bf16; int C; size_t lds_bytes;
+  SepSeg seg0;                               // the only segment of a single-segment launch (kernel argument)
+  int nseg; int B; int total_tiles; int bf16; int C;
+  size_t off_atile, off_wdw, off_bias, lds_bytes;   // LDS layout (k_sep.hip: sep_lds_layout)
 };
 
 // ---- decode: boxes + translation from raw heads (loss.py:12-51) ----
@@ -102,5 +105,5 @@ void launch_decode(const DecodeArgs&, hipStream_t);
 void launch_export(const ExportArgs&, hipStream_t);
 void launch_filter(const FilterArgs&, hipStream_t);
 int dw_blocks_per_image(int Ho, int Wo, int C, int TW);
-size_t sep_lds_bytes(int C, int bf16);
+void sep_lds_layout(int C, int bf16, int ts, int max_cols_f32, int max_cols_map, SepArgs* a);
 int sep_prepare(void);   // raises the dynamic-LDS limit of the sepconv kernels (call once per device)

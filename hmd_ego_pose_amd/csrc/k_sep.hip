@@ -8,99 +8,146 @@
 // `conv(feat); bn(feat); swish(feat)` / the header conv + permute/view/cat
 // (efficientdet/model.py:361-417; hmdegopose/model.py:55-90,127-156,191-228).
 //
-// One workgroup (8 waves) = one 8x8 output tile of one image of one "segment" (a node, or one
-// (head, level, column-chunk) triple); a single launch covers every segment of a layer, e.g. all
-// 5 heads x 5 levels of tower layer i.  These maps are tiny (32x32 .. 2x2 per image), so the
-// kernel is latency-bound: the design goal is the shortest dependent chain per workgroup.
+// One workgroup (16 waves) = one TSxTS output tile (TS = 16 on maps >= 16x16, else 8) of one
+// image of one "segment" (a node, or one (head, level, column-chunk) triple); a single launch
+// covers every segment of a layer, e.g. all 5 heads x 5 levels of a tower layer.  These maps are
+// tiny (32x32 .. 2x2 per image), so the kernel is latency-bound: the design goal is the shortest
+// dependent chain per workgroup and full-line stores.
 //   phase 0  issue the first pointwise-weight fragments (registers) and copy the depthwise
-//            weights + bias to LDS - nothing below depends on them until phase 3
-//   phase 1  fused (+swish) 10x10 halo of the depthwise input -> LDS fp32, zero outside the map
-//   phase 2  depthwise 3x3 from LDS -> MFMA operand tile [64 pixels][C] in LDS
+//            weights + bias to LDS - nothing below depends on them until phase 2/3
+//   phase 1  fused (+swish) (TS+2)^2 halo of the depthwise input -> LDS (dtype), zero outside the
+//            map; all gather loads of an item are issued before the first is consumed
+//   phase 2  depthwise 3x3 from LDS -> MFMA operand tile [TS*TS pixels][C] in LDS
 //   phase 3  1x1 conv as the transposed MFMA product of k_pw.hip (W fragment = A operand,
-//            pixels = B operand); (m-tile, n-tile) pairs are dealt round-robin to the 8 waves and
-//            the weight fragments run 4 deep ahead of the MFMAs in a register ring.
-// Head outputs are written directly at their anchor offset in the [B, N_anchors, K] result (no
-// permute / cat pass).
+//            pixels = B operand); (m-tile, n-tile) pairs are dealt round-robin to the 16 waves, the
+//            weight fragments run 4 deep ahead of the MFMAs in a register ring; results go to an
+//            LDS output tile (over the dead halo)
+//   phase 4  the output tile leaves as full coalesced rows.  Head outputs land directly at their
+//            anchor offset in the [B, N_anchors, K] result (no permute / cat pass).
 #include <type_traits>
 
 #include "hep_dev.h"
 #include "hep_internal.h"
 
-#define SEP_THREADS 512
-#define SEP_WAVES 8
+// BiFPN nodes (single segment, <= 256 workgroups, pure latency): 16 waves per workgroup.
+// Head layers (25-40 segments, ~2000 workgroups, throughput): 8 waves so two workgroups share a CU.
+#define SEP_THREADS_OF(single) ((single) ? 1024 : 512)
 
-__host__ __device__ static inline int sep_cp(int C) { return C + 4; }                 // halo row pitch (floats)
-__host__ __device__ static inline int sep_ca(int C, int bf16) { return bf16 ? C + 8 : C + 4; }
-__host__ __device__ static inline size_t sep_off_atile(int C) { return (size_t)100 * sep_cp(C) * 4; }
-__host__ __device__ static inline size_t sep_off_wdw(int C, int bf16) { return sep_off_atile(C) + (size_t)64 * sep_ca(C, bf16) * (bf16 ? 2 : 4); }
-__host__ __device__ static inline size_t sep_off_bias(int C, int bf16) { return sep_off_wdw(C, bf16) + (size_t)9 * C * 4; }
+// 8 channels as loaded (bf16: one 16-byte vector = 4 VGPRs; fp32: two)
+template <bool BF16> struct Raw8;
+template <> struct Raw8<true> {
+  u32x4 v;
+  __device__ __forceinline__ void zero() { v = (u32x4){0, 0, 0, 0}; }
+  __device__ __forceinline__ void load(const void* base, int64_t idx) { v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(base) + idx); }
+  __device__ __forceinline__ float get(int c) const { return (c & 1) ? __uint_as_float(v[c >> 1] & 0xffff0000u) : __uint_as_float(v[c >> 1] << 16); }
+};
+template <> struct Raw8<false> {
+  f32x4 a, b;
+  __device__ __forceinline__ void zero() { a = (f32x4){0.f, 0.f, 0.f, 0.f}; b = a; }
+  __device__ __forceinline__ void load(const void* base, int64_t idx) {
+    const f32x4* p = reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(base) + idx); a = p[0]; b = p[1];
+  }
+  __device__ __forceinline__ float get(int c) const { return c < 4 ? a[c] : b[c - 4]; }
+};
 
-size_t sep_lds_bytes(int C, int bf16) { return sep_off_bias(C, bf16) + (size_t)SEP_MAX_TILES_N * 16 * 4; }
-
+// fused value of 8 channels at (y, x): sum_i fw_i * gather_i, optional swish.  Every load of the
+// item is issued before the first one is consumed (one memory round trip per item in bf16; the
+// fp32 parity mode walks the max-pool window row by row to stay inside the register budget).
 template <bool BF16>
-__device__ __forceinline__ void gather_src(const SepSeg& sg, int i, int b, int y, int x, int c0, float v[8]) {
-  typedef Vec8<BF16> V;
-  const int C = sg.C, sh = sg.sh[i], sw = sg.sw[i];
-  const int64_t img = (int64_t)b * sh * sw * C;
-  if (sg.kind[i] == SRC_SAME) {
-    V::load(sg.src[i], img + ((int64_t)y * sw + x) * C + c0, v);
-  } else if (sg.kind[i] == SRC_UP) {
-    V::load(sg.src[i], img + ((int64_t)(y >> 1) * sw + (x >> 1)) * C + c0, v);
-  } else {   // SRC_DOWN: 3x3/2 max-pool, zero padding takes part in the max
-    // one row of the window (3 loads in flight) at a time keeps the register footprint small
+__device__ __forceinline__ void gather_fuse(const SepSeg& sg, int b, int y, int x, int c0, float v[8]) {
+  const int C = sg.C;
+  constexpr int ROWS = BF16 ? 3 : 1;        // window rows in flight at once
+  Raw8<BF16> same[HEP_MAX_SRC];
+  Raw8<BF16> win[ROWS * 3];
+  // (the descriptor's arrays are only ever indexed by unrolled constants: a run-time index would
+  //  push the whole by-value struct out of scalar registers into scratch memory)
+  int down = -1, dsh = 0, dsw = 0, dpad = 0; const void* dsrc = nullptr;
 #pragma unroll
-    for (int ky = 0; ky < 3; ky++) {
-      float t[3][8];
+  for (int i = 0; i < HEP_MAX_SRC; i++) {
+    if (i >= sg.nsrc) break;
+    const int sh = sg.sh[i], sw = sg.sw[i];
+    const int64_t img = (int64_t)b * sh * sw * C;
+    if (sg.kind[i] == SRC_SAME) same[i].load(sg.src[i], img + ((int64_t)y * sw + x) * C + c0);
+    else if (sg.kind[i] == SRC_UP) same[i].load(sg.src[i], img + ((int64_t)(y >> 1) * sw + (x >> 1)) * C + c0);
+    else { down = i; dsh = sh; dsw = sw; dpad = sg.pool_pad[i]; dsrc = sg.src[i]; }   // SRC_DOWN (at most one per node)
+  }
+  float pooled[8];
+  if (down >= 0) {
+    const int sh = dsh, sw = dsw;
+    const int64_t img = (int64_t)b * sh * sw * C;
 #pragma unroll
-      for (int kx = 0; kx < 3; kx++) {
-        const int iy = 2 * y - sg.pool_pad[i] + ky, ix = 2 * x - sg.pool_pad[i] + kx;
+    for (int r0 = 0; r0 < 3; r0 += ROWS) {
 #pragma unroll
-        for (int c = 0; c < 8; c++) t[kx][c] = 0.f;
-        if (iy >= 0 && iy < sh && ix >= 0 && ix < sw) V::load(sg.src[i], img + ((int64_t)iy * sw + ix) * C + c0, t[kx]);
+      for (int q = 0; q < ROWS * 3; q++) {
+        const int iy = 2 * y - dpad + r0 + q / 3, ix = 2 * x - dpad + q % 3;
+        win[q].zero();
+        if (iy >= 0 && iy < sh && ix >= 0 && ix < sw) win[q].load(dsrc, img + ((int64_t)iy * sw + ix) * C + c0);
       }
 #pragma unroll
       for (int c = 0; c < 8; c++) {
-        const float m = fmaxf(fmaxf(t[0][c], t[1][c]), t[2][c]);
-        v[c] = ky == 0 ? m : fmaxf(v[c], m);
+        float m = win[0].get(c);
+#pragma unroll
+        for (int q = 1; q < ROWS * 3; q++) m = fmaxf(m, win[q].get(c));
+        pooled[c] = r0 == 0 ? m : fmaxf(pooled[c], m);
       }
     }
   }
+#pragma unroll
+  for (int c = 0; c < 8; c++) v[c] = 0.f;
+#pragma unroll
+  for (int i = 0; i < HEP_MAX_SRC; i++) {
+    if (i >= sg.nsrc) break;
+#pragma unroll
+    for (int c = 0; c < 8; c++) v[c] = fmaf(sg.fw[i], i == down ? pooled[c] : same[i].get(c), v[c]);
+  }
+  if (sg.pre_act) {
+#pragma unroll
+    for (int c = 0; c < 8; c++) v[c] = swishf(v[c]);
+  }
 }
 
-template <bool BF16>
-__global__ __launch_bounds__(SEP_THREADS, 4) void sep_kernel(SepArgs a) {
+template <bool BF16, bool SINGLE>
+__global__ __launch_bounds__(SEP_THREADS_OF(SINGLE), 4) void sep_kernel(SepArgs a) {
+  constexpr int SEP_THREADS = SEP_THREADS_OF(SINGLE), SEP_WAVES = SEP_THREADS / 64;
   typedef Vec8<BF16> V;
   typedef typename V::elem T;
   typedef typename std::conditional<BF16, u32x4, f32x4>::type raw_t;
-  constexpr int KSTEP = BF16 ? 32 : 16, KLANE = BF16 ? 8 : 4;
+  constexpr int KSTEP = BF16 ? 32 : 16, KLANE = BF16 ? 8 : 4, PAD = BF16 ? 8 : 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  // ---- locate the segment and tile ----
-  // one table lookup, then the whole descriptor by VALUE: it lands in scalar registers once, instead
-  // of being re-read from global memory (a dependent round trip) at every use after a barrier
-  const SepSeg sg = a.segs[a.tile_seg[blockIdx.x]];
-  const int C = sg.C, CG = C >> 3, h = sg.h, w = sg.w;
+  // the segment descriptor is never re-read from global memory: single-segment launches (BiFPN
+  // nodes) take it from the kernel arguments (scalar loads), multi-segment launches (heads) copy
+  // theirs into LDS once
+  __shared__ SepSeg seg_s;
+  if (!SINGLE) {
+    const int si = a.tile_seg[blockIdx.x];
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(a.segs + si);
+    if (threadIdx.x < sizeof(SepSeg) / 4) reinterpret_cast<uint32_t*>(&seg_s)[threadIdx.x] = src[threadIdx.x];
+    __syncthreads();
+  }
+  const SepSeg& sg = SINGLE ? a.seg0 : seg_s;
+  const int C = sg.C, CG = C >> 3, h = sg.h, w = sg.w, TS = sg.ts, HS = TS + 2;
   const int t = blockIdx.x - sg.tile_begin;
   const int b = blockIdx.y;                 // grid = (tiles of one image over all segments, batch)
-  const int y0 = (t / sg.tiles_x) * 8, x0 = (t % sg.tiles_x) * 8;
-  const int CP = sep_cp(C), CA = sep_ca(C, BF16);
-  float* halo = reinterpret_cast<float*>(smem);
-  T* atile = reinterpret_cast<T*>(smem + sep_off_atile(C));
-  float* wdw_s = reinterpret_cast<float*>(smem + sep_off_wdw(C, BF16));
-  float* bias_s = reinterpret_cast<float*>(smem + sep_off_bias(C, BF16));
+  const int y0 = (t / sg.tiles_x) * TS, x0 = (t % sg.tiles_x) * TS;
+  const int CH = C + PAD;                   // halo and operand-tile row pitch (elements)
+  T* halo = reinterpret_cast<T*>(smem);
+  T* atile = reinterpret_cast<T*>(smem + a.off_atile);
+  float* wdw_s = reinterpret_cast<float*>(smem + a.off_wdw);
+  float* bias_s = reinterpret_cast<float*>(smem + a.off_bias);
 
   // ---- phase 0: weight prefetch (independent of the activations) ----
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, g = lane >> 4;
-  const int rows_valid = min(8, h - y0);
-  const int mtv = (rows_valid + 1) >> 1;                // m-tiles (2 tile rows = 16 pixels) with any valid pixel
+  const int rows_valid = min(TS, h - y0), cols_valid = min(TS, w - x0);
+  const int mtv = TS == 16 ? rows_valid : (rows_valid + 1) >> 1;   // 16-pixel m-tiles holding a valid pixel
   const int ksteps = (C + KSTEP - 1) / KSTEP;
-  const int nitems = mtv * sg.tilesN * ksteps;          // (pair, kstep) items; pair = nt * mtv + mt
+  const int npairs = mtv * sg.tilesN;                              // pair = nt * mtv + mt
   const T* W = reinterpret_cast<const T*>(sg.wpw);
-  auto wload = [&](int it) -> raw_t {                   // it = this wave's it-th (pair, kstep)
+  auto wload = [&](int it) -> raw_t {                              // it = this wave's it-th (pair, kstep)
     raw_t v = {};
     const int pair = wave + SEP_WAVES * (it / ksteps), ks = it % ksteps;
     const int k = ks * KSTEP + KLANE * g;
-    if (pair < mtv * sg.tilesN && k < C) v = *reinterpret_cast<const raw_t*>(W + (int64_t)((pair / mtv) * 16 + r) * C + k);
+    if (pair < npairs && k < C) v = *reinterpret_cast<const raw_t*>(W + (int64_t)((pair / mtv) * 16 + r) * C + k);
     return v;
   };
   raw_t wring[4];
@@ -109,53 +156,41 @@ __global__ __launch_bounds__(SEP_THREADS, 4) void sep_kernel(SepArgs a) {
   for (int i = threadIdx.x; i < 9 * C; i += SEP_THREADS) wdw_s[i] = sg.wdw[i];
   for (int i = threadIdx.x; i < sg.tilesN * 16; i += SEP_THREADS) bias_s[i] = sg.bias[i];
 
-  // ---- phase 1: fused (+swish) 10x10 halo of the depthwise input, zero outside the image ----
-  for (int item = threadIdx.x; item < 100 * CG; item += SEP_THREADS) {
+  // ---- phase 1: fused (+swish) halo of the depthwise input, zero outside the image ----
+  for (int item = threadIdx.x; item < HS * HS * CG; item += SEP_THREADS) {
     const int pos = item / CG, cg = item % CG;
-    const int y = y0 + pos / 10 - 1, x = x0 + pos % 10 - 1;
+    const int y = y0 + pos / HS - 1, x = x0 + pos % HS - 1;
     float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (y >= 0 && y < h && x >= 0 && x < w) {
-#pragma unroll
-      for (int i = 0; i < HEP_MAX_SRC; i++) {
-        if (i >= sg.nsrc) break;
-        float s[8];
-        gather_src<BF16>(sg, i, b, y, x, cg * 8, s);
-#pragma unroll
-        for (int c = 0; c < 8; c++) v[c] = fmaf(sg.fw[i], s[c], v[c]);
-      }
-      if (sg.pre_act) {
-#pragma unroll
-        for (int c = 0; c < 8; c++) v[c] = swishf(v[c]);
-      }
-    }
-    f32x4* hp = reinterpret_cast<f32x4*>(halo + pos * CP + cg * 8);
-    hp[0] = (f32x4){v[0], v[1], v[2], v[3]};
-    hp[1] = (f32x4){v[4], v[5], v[6], v[7]};
+    if (y >= 0 && y < h && x >= 0 && x < w) gather_fuse<BF16>(sg, b, y, x, cg * 8, v);
+    V::store(halo, (int64_t)pos * CH + cg * 8, v);
   }
   __syncthreads();
 
-  // ---- phase 2: depthwise 3x3 -> operand tile [64 pixels][C] ----
-  for (int item = threadIdx.x; item < 64 * CG; item += SEP_THREADS) {
+  // ---- phase 2: depthwise 3x3 -> operand tile [TS*TS pixels][C] ----
+  for (int item = threadIdx.x; item < TS * TS * CG; item += SEP_THREADS) {
     const int p = item / CG, cg = item % CG;
-    const int py = p >> 3, px = p & 7;
+    const int py = p / TS, px = p % TS;
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int ky = 0; ky < 3; ky++)
 #pragma unroll
       for (int kx = 0; kx < 3; kx++) {
-        const f32x4* hp = reinterpret_cast<const f32x4*>(halo + ((py + ky) * 10 + px + kx) * CP + cg * 8);
+        float hv[8];
+        V::load(halo, (int64_t)((py + ky) * HS + px + kx) * CH + cg * 8, hv);
         const f32x4* wp = reinterpret_cast<const f32x4*>(wdw_s + (ky * 3 + kx) * C + cg * 8);
-        const f32x4 h0 = hp[0], h1 = hp[1], w0 = wp[0], w1 = wp[1];
+        const f32x4 w0 = wp[0], w1 = wp[1];
 #pragma unroll
-        for (int c = 0; c < 4; c++) { acc[c] = fmaf(h0[c], w0[c], acc[c]); acc[4 + c] = fmaf(h1[c], w1[c], acc[4 + c]); }
+        for (int c = 0; c < 4; c++) { acc[c] = fmaf(hv[c], w0[c], acc[c]); acc[4 + c] = fmaf(hv[4 + c], w1[c], acc[4 + c]); }
       }
-    V::store(atile, (int64_t)p * CA + cg * 8, acc);
+    V::store(atile, (int64_t)p * CH + cg * 8, acc);
   }
-  __syncthreads();
+  __syncthreads();      // halo is dead from here on: its LDS becomes the output tile
 
-  // ---- phase 3: pointwise conv, D[n, pixel] = W[n,:] . tile[pixel,:] ----
-  const int my_pairs = (mtv * sg.tilesN - wave + SEP_WAVES - 1) / SEP_WAVES;    // pairs wave, wave+8, ...
-  if (my_pairs <= 0) return;
+  // ---- phase 3: pointwise conv, D[n, pixel] = W[n,:] . tile[pixel,:] -> LDS output tile ----
+  const int Nc = sg.N;                                    // columns of this segment
+  float* otile_f = reinterpret_cast<float*>(smem);        // [TS*TS][Nc] fp32 (head outputs)
+  T* otile_t = reinterpret_cast<T*>(smem);                // [TS*TS][Nc] dtype (maps)
+  const int my_pairs = npairs > wave ? (npairs - wave + SEP_WAVES - 1) / SEP_WAVES : 0;
   const int my_items = my_pairs * ksteps;
   f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
   auto step = [&](int it, raw_t wfrag) {
@@ -164,7 +199,7 @@ __global__ __launch_bounds__(SEP_THREADS, 4) void sep_kernel(SepArgs a) {
     const int m = mt * 16 + r;
     const int k = ks * KSTEP + KLANE * g;
     raw_t xa = {};
-    if (k < C) xa = *reinterpret_cast<const raw_t*>(atile + (int64_t)m * CA + k);
+    if (k < C) xa = *reinterpret_cast<const raw_t*>(atile + (int64_t)m * CH + k);
     if constexpr (BF16) {
       acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wfrag), __builtin_bit_cast(bf16x8, xa), acc, 0, 0, 0);
     } else {
@@ -172,24 +207,17 @@ __global__ __launch_bounds__(SEP_THREADS, 4) void sep_kernel(SepArgs a) {
       for (int q = 0; q < 4; q++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wfrag[q], xa[q], acc, 0, 0, 0);
     }
     if (ks != ksteps - 1) return;
-    // ---- epilogue of this (m-tile, n-tile) pair ----
-    const int y = y0 + (m >> 3), x = x0 + (m & 7);
-    const int n = nt * 16 + 4 * g;
-    if (y < h && x < w && n < sg.N) {
+    const int n = nt * 16 + 4 * g;          // lane: 4 consecutive columns of pixel m
+    if (n < Nc) {
       const f32x4 bias = *reinterpret_cast<const f32x4*>(bias_s + n);
       float v[4];
 #pragma unroll
       for (int q = 0; q < 4; q++) v[q] = apply_act(acc[q] + bias[q], sg.act);
-      const int64_t obase = (int64_t)b * sg.out_bstride + sg.out_off + ((int64_t)y * w + x) * sg.out_rowstride;
       if (sg.out_f32) {
-        float* o = reinterpret_cast<float*>(sg.out) + obase;
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const int nn = n + q + sg.n_base;
-          if (n + q < sg.N) o[(nn / sg.col_kin) * sg.col_kout + nn % sg.col_kin + sg.col_off] = v[q];
-        }
+        for (int q = 0; q < 4; q++) if (n + q < Nc) otile_f[(int64_t)m * Nc + n + q] = v[q];
       } else {
-        V::store4(sg.out, obase + n, v);     // N is a multiple of 8 for every non-header layer
+        V::store4(otile_t, (int64_t)m * Nc + n, v);     // Nc is a multiple of 8 for every map-producing layer
       }
     }
     acc = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -204,19 +232,70 @@ __global__ __launch_bounds__(SEP_THREADS, 4) void sep_kernel(SepArgs a) {
       }
     }
   }
-  (void)nitems;
+  __syncthreads();
+
+  // ---- phase 4: coalesced copy-out ----
+  if (sg.out_f32) {
+    // head result [B, N_anchors, K]: pixel p owns 9*K consecutive floats; this segment's Nc columns
+    float* o = reinterpret_cast<float*>(sg.out) + (int64_t)b * sg.out_bstride + sg.out_off;
+    const int npx = rows_valid * cols_valid;
+    for (int pp = wave; pp < npx; pp += SEP_WAVES) {
+      const int py = pp / cols_valid, px = pp % cols_valid;
+      const int m = TS == 16 ? py * 16 + px : py * 8 + px;
+      float* orow = o + ((int64_t)(y0 + py) * w + x0 + px) * sg.out_rowstride;
+      for (int c = lane; c < Nc; c += 64) {
+        const int nn = c + sg.n_base;
+        orow[(nn / sg.col_kin) * sg.col_kout + nn % sg.col_kin + sg.col_off] = otile_f[(int64_t)m * Nc + c];
+      }
+    }
+  } else {
+    // NHWC map: a tile row of cols_valid pixels x Nc channels is one contiguous run
+    T* o = reinterpret_cast<T*>(sg.out) + (int64_t)b * sg.out_bstride + sg.out_off;
+    const int vec_per_row = TS * Nc / 8, vec_valid = cols_valid * Nc / 8;
+    for (int idx = threadIdx.x; idx < rows_valid * vec_per_row; idx += SEP_THREADS) {
+      const int py = idx / vec_per_row, v = idx % vec_per_row;
+      if (v >= vec_valid) continue;
+      const u32x4 val = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(otile_t) + ((int64_t)py * TS * Nc + v * 8) * sizeof(T));
+      const int64_t dst = ((int64_t)(y0 + py) * w + x0) * Nc + v * 8;
+      if constexpr (BF16) {
+        *reinterpret_cast<u32x4*>(o + dst) = val;
+      } else {    // fp32: 8 elements = two 16-byte vectors
+        const u32x4 val2 = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(otile_t) + ((int64_t)py * TS * Nc + v * 8) * sizeof(T) + 16);
+        *reinterpret_cast<u32x4*>(o + dst) = val;
+        *reinterpret_cast<u32x4*>(o + dst + 4) = val2;
+      }
+    }
+  }
+}
+
+void sep_lds_layout(int C, int bf16, int ts, int max_cols_f32, int max_cols_map, SepArgs* a) {
+  const size_t es = bf16 ? 2 : 4, pad = bf16 ? 8 : 4;
+  const size_t hs = ts + 2, px = (size_t)ts * ts;
+  size_t region = hs * hs * (C + pad) * es;                              // halo ...
+  region = std::max(region, px * (size_t)max_cols_f32 * 4);              // ... or the fp32 output tile
+  region = std::max(region, px * (size_t)max_cols_map * es);             // ... or the dtype output tile
+  region = (region + 15) & ~(size_t)15;
+  a->off_atile = region;
+  a->off_wdw = a->off_atile + px * (C + pad) * es;
+  a->off_bias = a->off_wdw + (size_t)9 * C * 4;
+  a->lds_bytes = a->off_bias + (size_t)SEP_MAX_TILES_N * 16 * 4;
 }
 
 int sep_prepare(void) {
-  hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(sep_kernel<true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(sep_kernel<false>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  return (e1 == hipSuccess && e2 == hipSuccess) ? 0 : -1;
+  const void* fns[4] = {reinterpret_cast<const void*>(sep_kernel<true, true>), reinterpret_cast<const void*>(sep_kernel<true, false>),
+                        reinterpret_cast<const void*>(sep_kernel<false, true>), reinterpret_cast<const void*>(sep_kernel<false, false>)};
+  for (const void* f : fns)
+    if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024) != hipSuccess) return -1;
+  return 0;
 }
 
 void launch_sep(const SepArgs& a, hipStream_t s) {
   dim3 grid(a.total_tiles, a.B);
-  if (a.bf16) hipLaunchKernelGGL(sep_kernel<true>, grid, dim3(SEP_THREADS), a.lds_bytes, s, a);
-  else hipLaunchKernelGGL(sep_kernel<false>, grid, dim3(SEP_THREADS), a.lds_bytes, s, a);
+  if (a.bf16) {
+    if (a.nseg == 1) hipLaunchKernelGGL((sep_kernel<true, true>), grid, dim3(SEP_THREADS_OF(true)), a.lds_bytes, s, a);
+    else hipLaunchKernelGGL((sep_kernel<true, false>), grid, dim3(SEP_THREADS_OF(false)), a.lds_bytes, s, a);
+  } else {
+    if (a.nseg == 1) hipLaunchKernelGGL((sep_kernel<false, true>), grid, dim3(SEP_THREADS_OF(true)), a.lds_bytes, s, a);
+    else hipLaunchKernelGGL((sep_kernel<false, false>), grid, dim3(SEP_THREADS_OF(false)), a.lds_bytes, s, a);
+  }
 }
