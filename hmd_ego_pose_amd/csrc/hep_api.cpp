@@ -2,6 +2,7 @@
 // eager stem launch (it reads the caller's input pointer) + one captured hipGraph for
 // everything behind it, replayed on the caller's stream.
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <fstream>
@@ -23,8 +24,11 @@ static const int kOutK[5] = {4, 1, 3, 3, 63};
 namespace hep {
 
 Session::~Session() {
-  for (auto& g : graphs) hipGraphExecDestroy(g.second);
-  for (Op& o : ops) if (o.kind == OP_SEP) { hipFree((void*)o.sep.segs); hipFree((void*)o.sep.tile_seg); }
+  for (auto& g : graphs) for (hipGraphExec_t ge : g.second) hipGraphExecDestroy(ge);
+  for (auto& lo : lane_ops) for (Op& o : lo) if (o.kind == OP_SEP) { hipFree((void*)o.sep.segs); hipFree((void*)o.sep.tile_seg); }
+  for (hipStream_t st : lane_streams) hipStreamDestroy(st);
+  for (hipEvent_t ev : lane_events) hipEventDestroy(ev);
+  if (fork_event) hipEventDestroy(fork_event);
   hipFree(d_weights); hipFree(d_arena);
   for (int i = 0; i < 5; i++) { hipFree(d_out[i]); hipFree(d_feat_nchw[i]); }
   hipFree(d_in); hipFree(d_anchors); hipFree(d_tanchors); hipFree(d_boxes); hipFree(d_trans); hipFree(d_cam);
@@ -47,29 +51,50 @@ void launch_op(const Session& s, const Op& op, int batch, hipStream_t st, const 
   }
 }
 
-// forward = ops[0] (stem, eager: its input pointer belongs to the caller) + graph(ops[1..])
+// forward = per lane: ops[0] (stem, eager: its input pointer belongs to the caller) + the rest inside
+// ONE hipGraph whose lanes are parallel branches (fork/join captured through events)
 int run_forward(Session* s, const float* in_dev, const int64_t* strides, int batch, hipStream_t st, std::string* err) {
   const int64_t S = s->size;
   const int64_t contiguous[4] = {3 * S * S, S * S, S, 1};
   if (!strides) strides = contiguous;
-  launch_op(*s, s->ops[0], batch, st, in_dev, strides);
+  const int nl = s->lanes_for(batch);
+  for (int l = 0; l < nl; l++)
+    launch_op(*s, s->lane_ops[l][0], s->lane_count(batch, l), st, in_dev + (int64_t)l * s->lane_batch * strides[0], strides);
   if (s->flags & HEP_FLAG_NO_GRAPH) {
-    for (size_t i = 1; i < s->ops.size(); i++) launch_op(*s, s->ops[i], batch, st, nullptr, nullptr);
+    for (int l = 0; l < nl; l++)
+      for (size_t i = 1; i < s->ops.size(); i++) launch_op(*s, s->lane_ops[l][i], s->lane_count(batch, l), st, nullptr, nullptr);
   } else {
+    // one captured graph per lane, replayed on the lane's own stream so that the lanes' kernel
+    // chains overlap on the device; the caller's stream forks into the lane streams and joins them
     auto it = s->graphs.find(batch);
     if (it == s->graphs.end()) {
-      hipGraph_t g; hipGraphExec_t ge;
-      hipError_t e = hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal);
-      if (e != hipSuccess) { *err = std::string("hipStreamBeginCapture: ") + hipGetErrorString(e); return HEP_ERR_DEVICE; }
-      for (size_t i = 1; i < s->ops.size(); i++) launch_op(*s, s->ops[i], batch, s->stream, nullptr, nullptr);
-      e = hipStreamEndCapture(s->stream, &g);
-      if (e != hipSuccess) { *err = std::string("hipStreamEndCapture: ") + hipGetErrorString(e); return HEP_ERR_DEVICE; }
-      e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
-      hipGraphDestroy(g);
-      if (e != hipSuccess) { *err = std::string("hipGraphInstantiate: ") + hipGetErrorString(e); return HEP_ERR_DEVICE; }
-      it = s->graphs.emplace(batch, ge).first;
+      std::vector<hipGraphExec_t> execs;
+      for (int l = 0; l < nl; l++) {
+        hipGraph_t g; hipGraphExec_t ge;
+        hipError_t e = hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal);
+        if (e != hipSuccess) { *err = std::string("hipStreamBeginCapture: ") + hipGetErrorString(e); return HEP_ERR_DEVICE; }
+        for (size_t i = 1; i < s->ops.size(); i++) launch_op(*s, s->lane_ops[l][i], s->lane_count(batch, l), s->stream, nullptr, nullptr);
+        e = hipStreamEndCapture(s->stream, &g);
+        if (e != hipSuccess) { *err = std::string("hipStreamEndCapture: ") + hipGetErrorString(e); return HEP_ERR_DEVICE; }
+        e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+        hipGraphDestroy(g);
+        if (e != hipSuccess) { *err = std::string("hipGraphInstantiate: ") + hipGetErrorString(e); return HEP_ERR_DEVICE; }
+        execs.push_back(ge);
+      }
+      it = s->graphs.emplace(batch, execs).first;
     }
-    hipError_t e = hipGraphLaunch(it->second, st);
+    hipError_t e = hipSuccess;
+    if (nl == 1) e = hipGraphLaunch(it->second[0], st);
+    else {
+      e = hipEventRecord(s->fork_event, st);
+      for (int l = 0; l < nl && e == hipSuccess; l++) {
+        hipStream_t ls = s->lane_streams[l];
+        e = hipStreamWaitEvent(ls, s->fork_event, 0);
+        if (e == hipSuccess) e = hipGraphLaunch(it->second[l], ls);
+        if (e == hipSuccess) e = hipEventRecord(s->lane_events[l], ls);
+        if (e == hipSuccess) e = hipStreamWaitEvent(st, s->lane_events[l], 0);
+      }
+    }
     if (e != hipSuccess) { *err = std::string("hipGraphLaunch: ") + hipGetErrorString(e); return HEP_ERR_DEVICE; }
   }
   hipError_t e = hipGetLastError();
@@ -112,6 +137,13 @@ int hep_create_from_memory(const void* pack, size_t pack_bytes, int phi, int siz
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
     return fail(HEP_ERR_DEVICE, std::string("device is ") + prop.gcnArchName + ", libhep is built for gfx950 (MI355X) only");
   s.size = size; s.max_batch = max_batch; s.dtype = dtype; s.device = device; s.flags = flags;
+  {   // lanes: slices of the batch that run as parallel graph branches (HEP_LANES overrides)
+    int lanes = 1;   // measured on MI355X at bs16: 2/4/8 lanes are 4 % / 75 % / 150 % SLOWER (kernels contend instead of overlapping)
+    if (const char* e = getenv("HEP_LANES")) lanes = atoi(e);
+    lanes = std::max(1, std::min(lanes, std::min(max_batch, 16)));
+    s.lane_batch = (max_batch + lanes - 1) / lanes;
+    s.lanes = (max_batch + s.lane_batch - 1) / s.lane_batch;
+  }
   Pack pk; std::string err;
   if (!pk.parse(pack, pack_bytes, &err)) return fail(HEP_ERR_PACK, err);
   int rc = build_session(&s, pk, &err);
@@ -167,8 +199,11 @@ static int export_feats(Session& s, int batch, float* const feats[5], bool devic
       if (!s.d_feat_nchw[l]) HIPRET(hipMalloc((void**)&s.d_feat_nchw[l], (size_t)s.max_batch * t.H * t.W * t.C * 4));
       dst = s.d_feat_nchw[l];
     }
-    ExportArgs a; a.in = s.tptr(s.feat_ids[l]); a.out = dst; a.B = batch; a.H = t.H; a.W = t.W; a.C = t.C; a.bf16 = s.dtype;
-    launch_export(a, st);
+    for (int ln = 0; ln < s.lanes_for(batch); ln++) {
+      ExportArgs a; a.in = s.tptr(s.feat_ids[l], ln); a.out = dst + (size_t)ln * s.lane_batch * t.H * t.W * t.C;
+      a.B = s.lane_count(batch, ln); a.H = t.H; a.W = t.W; a.C = t.C; a.bf16 = s.dtype;
+      launch_export(a, st);
+    }
     if (!device_dst) HIPRET(hipMemcpyAsync(feats[l], dst, n * 4, hipMemcpyDeviceToHost, st));
   }
   return 0;
@@ -353,11 +388,16 @@ int hep_debug_tensor(hep_handle* h, const char* name, int batch, float* out, siz
   std::lock_guard<std::mutex> lk(s.mu);
   HIPRET(hipSetDevice(s.device));
   HIPRET(hipDeviceSynchronize());
-  if (t.f32 || s.dtype == HEP_F32) { HIPRET(hipMemcpy(out, s.tptr(it->second), n * 4, hipMemcpyDeviceToHost)); }
-  else {
-    std::vector<uint16_t> tmp(n);
-    HIPRET(hipMemcpy(tmp.data(), s.tptr(it->second), n * 2, hipMemcpyDeviceToHost));
-    for (size_t i = 0; i < n; i++) { uint32_t u = (uint32_t)tmp[i] << 16; memcpy(&out[i], &u, 4); }
+  const size_t per = (size_t)t.H * t.W * t.C;
+  for (int ln = 0; ln < s.lanes_for(batch); ln++) {
+    const size_t cnt = (size_t)s.lane_count(batch, ln) * per;
+    float* dst = out + (size_t)ln * s.lane_batch * per;
+    if (t.f32 || s.dtype == HEP_F32) { HIPRET(hipMemcpy(dst, s.tptr(it->second, ln), cnt * 4, hipMemcpyDeviceToHost)); }
+    else {
+      std::vector<uint16_t> tmp(cnt);
+      HIPRET(hipMemcpy(tmp.data(), s.tptr(it->second, ln), cnt * 2, hipMemcpyDeviceToHost));
+      for (size_t i = 0; i < cnt; i++) { uint32_t u = (uint32_t)tmp[i] << 16; memcpy(&dst[i], &u, 4); }
+    }
   }
   return 0;
 }
@@ -367,8 +407,9 @@ int hep_kernel_info(const hep_handle* h, int batch, int i, const char** name, do
   if (!h || i < 0 || i >= (int)h->s.ops.size()) return fail(HEP_ERR_INVALID, "bad kernel index");
   const Op& o = h->s.ops[i];
   if (name) *name = o.name.c_str();
-  if (bytes) *bytes = o.act_bytes_per_image * batch + o.weight_bytes;
-  if (flops) *flops = o.flops_per_image * batch;
+  const int per_launch = std::min(batch, h->s.lane_batch);      // frames one launch of this kernel sees
+  if (bytes) *bytes = o.act_bytes_per_image * per_launch + o.weight_bytes;
+  if (flops) *flops = o.flops_per_image * per_launch;
   return 0;
 }
 
@@ -417,9 +458,9 @@ int hep_profile(hep_handle* h, int batch, int iters, float* total_ms_per_iter, f
     for (auto& e : ev) HIPRET(hipEventCreate(&e));
     std::vector<double> acc(n, 0.0);
     for (int i = 0; i < iters + 1; i++) {
-      for (size_t k = 0; k < n; k++) {
+      for (size_t k = 0; k < n; k++) {     // lane 0's launches (lane_batch frames each), one after the other
         HIPRET(hipEventRecord(ev[k], s.stream));
-        launch_op(s, s.ops[k], batch, s.stream, s.d_in, st);
+        launch_op(s, s.lane_ops[0][k], s.lane_count(batch, 0), s.stream, s.d_in, st);
       }
       HIPRET(hipEventRecord(ev[n], s.stream));
       HIPRET(hipEventSynchronize(ev[n]));

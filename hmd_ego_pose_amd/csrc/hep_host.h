@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <map>
 #include <mutex>
 #include <string>
@@ -55,6 +56,12 @@ struct Op {
 
 struct Session {
   Arch arch; int size, max_batch, dtype, device; unsigned flags;
+  // The batch is cut into `lanes` contiguous slices of lane_batch frames; every lane owns an arena and a
+  // patched copy of the plan, and the captured hipGraph runs the lanes as parallel branches: the
+  // forward is a chain of ~100 small latency-bound kernels, and independent chains overlap on the chip.
+  int lanes = 1, lane_batch = 1;
+  std::vector<std::vector<Op>> lane_ops; std::vector<hipStream_t> lane_streams; std::vector<hipEvent_t> lane_events;
+  hipEvent_t fork_event = nullptr;
   int levels[5]; int level_off[5]; int num_anchors;
   std::vector<TensorDesc> tensors;
   std::vector<Op> ops;
@@ -71,17 +78,19 @@ struct Session {
   uint64_t* d_keys = nullptr; int npow2 = 0;
   float* d_det = nullptr; size_t det_floats = 0;   // staging for host-buffer filter
   hipStream_t stream = nullptr;     // handle's own stream (host API, capture, profiling)
-  std::map<int, hipGraphExec_t> graphs;   // per batch size
+  std::map<int, std::vector<hipGraphExec_t>> graphs;   // per batch size: one graph per lane
   std::mutex mu;
   int last_batch = 0;
 
   ~Session();
-  void* tptr(int id) const { const TensorDesc& t = tensors[id]; return t.external ? t.ext_ptr : (void*)(d_arena + t.offset); }
+  void* tptr(int id, int lane = 0) const { const TensorDesc& t = tensors[id]; return t.external ? t.ext_ptr : (void*)(d_arena + (size_t)lane * arena_bytes + t.offset); }
+  int lanes_for(int batch) const { return (batch + lane_batch - 1) / lane_batch; }
+  int lane_count(int batch, int lane) const { return std::min(lane_batch, batch - lane * lane_batch); }
   size_t esize() const { return dtype == 1 ? 2 : 4; }
 };
 
 int build_session(Session* s, const Pack& pack, std::string* err);
-void launch_op(const Session& s, const Op& op, int batch, hipStream_t st, const float* in, const int64_t* strides);
+void launch_op(const Session& s, const Op& op, int batch, hipStream_t st, const float* in, const int64_t* strides);   // batch frames starting at `in`
 int run_forward(Session* s, const float* in_dev, const int64_t* strides, int batch, hipStream_t st, std::string* err);
 int host_anchors(int size, std::vector<float>* anchors, std::vector<float>* tanchors);
 

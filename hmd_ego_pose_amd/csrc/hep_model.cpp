@@ -249,7 +249,7 @@ struct Planner {
     // tile shape: as many n-tiles per wave as fit (<= 8) so the activation rows are streamed
     // as few times as possible; two m-tiles per wave when the layer has rows to spare
     {
-      const int64_t Mmax = (int64_t)HW * s->max_batch;
+      const int64_t Mmax = (int64_t)HW * s->lane_batch;      // rows one launch sees (one lane of the batch)
       const int64_t strips = (Mmax + 15) / 16;             // 16-row strips
       const int ksteps = (K + (s->dtype ? 32 : 16) - 1) / (s->dtype ? 32 : 16);
       auto clampi = [](int64_t v, int lo, int hi) { return (int)std::max<int64_t>(lo, std::min<int64_t>(hi, v)); };
@@ -580,7 +580,7 @@ int build_session(Session* s, const Pack& pack, std::string* err) {
       for (int t : s->ops[i].writes) {
         TensorDesc& td = s->tensors[t];
         if (td.first_op != i) continue;
-        const size_t need = ((td.bytes_per_image * s->max_batch) + 255) & ~(size_t)255;
+        const size_t need = ((td.bytes_per_image * s->lane_batch) + 255) & ~(size_t)255;
         bool placed = false;
         if (!keep)
           for (size_t f = 0; f < freelist.size(); f++)
@@ -598,7 +598,7 @@ int build_session(Session* s, const Pack& pack, std::string* err) {
         for (int t : touched) {
           TensorDesc& td = s->tensors[t];
           if (td.last_op != i) continue;
-          const size_t sz = ((td.bytes_per_image * s->max_batch) + 255) & ~(size_t)255;
+          const size_t sz = ((td.bytes_per_image * s->lane_batch) + 255) & ~(size_t)255;
           freelist.push_back({td.offset, sz});
           // coalesce neighbours
           std::sort(freelist.begin(), freelist.end(), [](const Free& a, const Free& b) { return a.off < b.off; });
@@ -619,7 +619,8 @@ int build_session(Session* s, const Pack& pack, std::string* err) {
   s->weights_bytes = P.wb.host.size();
   HIPCHK(hipMalloc((void**)&s->d_weights, s->weights_bytes));
   HIPCHK(hipMemcpy(s->d_weights, P.wb.host.data(), s->weights_bytes, hipMemcpyHostToDevice));
-  HIPCHK(hipMalloc((void**)&s->d_arena, std::max<size_t>(s->arena_bytes, 256)));
+  s->arena_bytes = (s->arena_bytes + 255) & ~(size_t)255;
+  HIPCHK(hipMalloc((void**)&s->d_arena, std::max<size_t>(s->arena_bytes * s->lanes, 256)));
   static const int outk[5] = {4, 1, 3, 3, 63};
   for (int i = 0; i < 5; i++) HIPCHK(hipMalloc((void**)&s->d_out[i], (size_t)s->max_batch * s->num_anchors * outk[i] * 4));
   {
@@ -627,57 +628,64 @@ int build_session(Session* s, const Pack& pack, std::string* err) {
     HIPCHK(hipMalloc((void**)&s->d_anchors, a.size() * 4)); HIPCHK(hipMemcpy(s->d_anchors, a.data(), a.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMalloc((void**)&s->d_tanchors, t.size() * 4)); HIPCHK(hipMemcpy(s->d_tanchors, t.data(), t.size() * 4, hipMemcpyHostToDevice));
   }
-  // ---- patch pointers ----
-  for (const Ref& r : P.refs) {
-    Op& o = s->ops[r.op];
-    void* ptr;
-    if (r.tensor >= 0) ptr = s->tptr(r.tensor);
-    else if (r.tensor <= -2) ptr = s->d_out[-(r.tensor + 2)];
-    else ptr = s->d_weights + r.woff;
-    switch (r.field) {
-      case F_STEM_W: o.stem.w = (const float*)ptr; break;
-      case F_STEM_B: o.stem.bias = (const float*)ptr; break;
-      case F_STEM_OUT: o.stem.out = ptr; break;
-      case F_PW_A: o.pw.A = ptr; break;
-      case F_PW_W: o.pw.W = ptr; break;
-      case F_PW_B: o.pw.bias = (const float*)ptr; break;
-      case F_PW_SE: o.pw.se = (const float*)ptr; break;
-      case F_PW_RES: o.pw.res = ptr; break;
-      case F_PW_OUT: o.pw.out = ptr; break;
-      case F_DW_IN: o.dw.in = ptr; break;
-      case F_DW_W: o.dw.w = (const float*)ptr; break;
-      case F_DW_B: o.dw.bias = (const float*)ptr; break;
-      case F_DW_OUT: o.dw.out = ptr; break;
-      case F_DW_PART: o.dw.partial = (float*)ptr; break;
-      case F_SE_PART: o.se.partial = (const float*)ptr; break;
-      case F_SE_WR: o.se.wr = (const float*)ptr; break;
-      case F_SE_BR: o.se.br = (const float*)ptr; break;
-      case F_SE_WE: o.se.we = (const float*)ptr; break;
-      case F_SE_BE: o.se.be = (const float*)ptr; break;
-      case F_SE_SCALE: o.se.scale = (float*)ptr; break;
-      case F_POOL_IN: o.pool.in = ptr; break;
-      case F_POOL_OUT: o.pool.out = ptr; break;
-      case F_SEG_SRC: o.segs[r.seg].src[r.idx] = ptr; break;
-      case F_SEG_WDW: o.segs[r.seg].wdw = (const float*)ptr; break;
-      case F_SEG_WPW: o.segs[r.seg].wpw = ptr; break;
-      case F_SEG_BIAS: o.segs[r.seg].bias = (const float*)ptr; break;
-      case F_SEG_OUT: o.segs[r.seg].out = ptr; break;
+  HIPCHK(hipEventCreateWithFlags(&s->fork_event, hipEventDisableTiming));
+  // ---- one patched copy of the plan per lane: own arena slice, own slice of the head outputs ----
+  s->lane_ops.assign(s->lanes, s->ops);
+  for (int lane = 0; lane < s->lanes; lane++) {
+    hipStream_t st; HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); s->lane_streams.push_back(st);
+    hipEvent_t ev; HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); s->lane_events.push_back(ev);
+    std::vector<Op>& ops = s->lane_ops[lane];
+    for (const Ref& r : P.refs) {
+      Op& o = ops[r.op];
+      void* ptr;
+      if (r.tensor >= 0) ptr = s->tptr(r.tensor, lane);
+      else if (r.tensor <= -2) { const int k = -(r.tensor + 2); ptr = s->d_out[k] + (size_t)lane * s->lane_batch * s->num_anchors * outk[k]; }
+      else ptr = s->d_weights + r.woff;
+      switch (r.field) {
+        case F_STEM_W: o.stem.w = (const float*)ptr; break;
+        case F_STEM_B: o.stem.bias = (const float*)ptr; break;
+        case F_STEM_OUT: o.stem.out = ptr; break;
+        case F_PW_A: o.pw.A = ptr; break;
+        case F_PW_W: o.pw.W = ptr; break;
+        case F_PW_B: o.pw.bias = (const float*)ptr; break;
+        case F_PW_SE: o.pw.se = (const float*)ptr; break;
+        case F_PW_RES: o.pw.res = ptr; break;
+        case F_PW_OUT: o.pw.out = ptr; break;
+        case F_DW_IN: o.dw.in = ptr; break;
+        case F_DW_W: o.dw.w = (const float*)ptr; break;
+        case F_DW_B: o.dw.bias = (const float*)ptr; break;
+        case F_DW_OUT: o.dw.out = ptr; break;
+        case F_DW_PART: o.dw.partial = (float*)ptr; break;
+        case F_SE_PART: o.se.partial = (const float*)ptr; break;
+        case F_SE_WR: o.se.wr = (const float*)ptr; break;
+        case F_SE_BR: o.se.br = (const float*)ptr; break;
+        case F_SE_WE: o.se.we = (const float*)ptr; break;
+        case F_SE_BE: o.se.be = (const float*)ptr; break;
+        case F_SE_SCALE: o.se.scale = (float*)ptr; break;
+        case F_POOL_IN: o.pool.in = ptr; break;
+        case F_POOL_OUT: o.pool.out = ptr; break;
+        case F_SEG_SRC: o.segs[r.seg].src[r.idx] = ptr; break;
+        case F_SEG_WDW: o.segs[r.seg].wdw = (const float*)ptr; break;
+        case F_SEG_WPW: o.segs[r.seg].wpw = ptr; break;
+        case F_SEG_BIAS: o.segs[r.seg].bias = (const float*)ptr; break;
+        case F_SEG_OUT: o.segs[r.seg].out = ptr; break;
+      }
     }
+    // segment tables to device
+    for (Op& o : ops)
+      if (o.kind == OP_SEP) {
+        SepSeg* d; HIPCHK(hipMalloc((void**)&d, o.segs.size() * sizeof(SepSeg)));
+        HIPCHK(hipMemcpy(d, o.segs.data(), o.segs.size() * sizeof(SepSeg), hipMemcpyHostToDevice));
+        o.sep.segs = d;
+        std::vector<int> tile_seg(o.sep.total_tiles);
+        for (size_t si = 0; si < o.segs.size(); si++)
+          for (int t = 0; t < o.segs[si].tiles_x * o.segs[si].tiles_y; t++) tile_seg[o.segs[si].tile_begin + t] = (int)si;
+        int* dt; HIPCHK(hipMalloc((void**)&dt, tile_seg.size() * sizeof(int)));
+        HIPCHK(hipMemcpy(dt, tile_seg.data(), tile_seg.size() * sizeof(int), hipMemcpyHostToDevice));
+        o.sep.tile_seg = dt;
+        o.sep.seg0 = o.segs[0];
+      }
   }
-  // segment tables to device (appended to a second small allocation)
-  for (Op& o : s->ops)
-    if (o.kind == OP_SEP) {
-      SepSeg* d; HIPCHK(hipMalloc((void**)&d, o.segs.size() * sizeof(SepSeg)));
-      HIPCHK(hipMemcpy(d, o.segs.data(), o.segs.size() * sizeof(SepSeg), hipMemcpyHostToDevice));
-      o.sep.segs = d;
-      std::vector<int> tile_seg(o.sep.total_tiles);
-      for (size_t si = 0; si < o.segs.size(); si++)
-        for (int t = 0; t < o.segs[si].tiles_x * o.segs[si].tiles_y; t++) tile_seg[o.segs[si].tile_begin + t] = (int)si;
-      int* dt; HIPCHK(hipMalloc((void**)&dt, tile_seg.size() * sizeof(int)));
-      HIPCHK(hipMemcpy(dt, tile_seg.data(), tile_seg.size() * sizeof(int), hipMemcpyHostToDevice));
-      o.sep.tile_seg = dt;
-      o.sep.seg0 = o.segs[0];
-    }
 #undef HIPCHK
   return 0;
 }
