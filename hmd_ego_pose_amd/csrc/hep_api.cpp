@@ -47,6 +47,7 @@ void launch_op(const Session& s, const Op& op, int batch, hipStream_t st, const 
     case OP_DW: { DwArgs a = op.dw; a.B = batch; launch_dw(a, st); break; }
     case OP_SE: { SeArgs a = op.se; a.B = batch; launch_se(a, st); break; }
     case OP_POOL: { PoolArgs a = op.pool; a.B = batch; launch_pool(a, st); break; }
+    case OP_MBF: { MbfArgs a = op.mbf; a.B = batch; launch_mbf(a, st); break; }
     case OP_SEP: { SepArgs a = op.sep; a.B = batch; launch_sep(a, st); break; }
   }
 }
@@ -425,6 +426,7 @@ int hep_kernel_symbol(const hep_handle* h, int i, const char** symbol) {
     case OP_DW: snprintf(tmp, sizeof tmp, "dw_kernel<%s, %d, %d, %d>", t, o.dw.k, o.dw.s, o.dw.TW); break;
     case OP_SE: snprintf(tmp, sizeof tmp, "se_kernel"); break;
     case OP_POOL: snprintf(tmp, sizeof tmp, "pool_kernel<%s>", t); break;
+    case OP_MBF: snprintf(tmp, sizeof tmp, "mbf_kernel<%s, %d, %d>", t, o.mbf.k, o.mbf.s); break;
     default: snprintf(tmp, sizeof tmp, "sep_kernel<%s>", t); break;
   }
   buf = tmp; *symbol = buf.c_str();

@@ -45,10 +45,10 @@ struct TensorDesc {
   void* ext_ptr = nullptr;
 };
 
-enum OpKind { OP_STEM, OP_PW, OP_DW, OP_SE, OP_POOL, OP_SEP };
+enum OpKind { OP_STEM, OP_PW, OP_DW, OP_SE, OP_POOL, OP_SEP, OP_MBF };
 struct Op {
   OpKind kind; std::string name;
-  StemArgs stem; PwArgs pw; DwArgs dw; SeArgs se; PoolArgs pool; SepArgs sep;
+  StemArgs stem; PwArgs pw; DwArgs dw; SeArgs se; PoolArgs pool; SepArgs sep; MbfArgs mbf;
   std::vector<SepSeg> segs;         // host copy (device copy uploaded at build)
   std::vector<int> reads, writes;   // tensor ids
   double act_bytes_per_image = 0, flops_per_image = 0, weight_bytes = 0;

@@ -47,6 +47,21 @@ struct SeArgs {
   int B, C, sq;
 };
 
+// ---- fused MBConv front: expand 1x1 (+BN,swish) -> depthwise kxk (+BN,swish) -> SE partial sums ----
+struct MbfArgs {
+  const void* in;      // [B,H,W,Cin]
+  const void* we;      // [ceil16(Cexp)][Cin] expand weight, BN0 folded (unused when !has_expand)
+  const float* be;     // [Cexp]
+  const float* wdw;    // [k*k][Cexp], BN1 folded
+  const float* bdw;    // [Cexp]
+  void* out;           // [B,Ho,Wo,Cexp]
+  float* partial;      // [B][tiles][Cexp]
+  int B, H, W, Cin, Cexp, Ho, Wo, k, s, pad_t, pad_l, has_expand, bf16;
+  int CC;              // expanded channels per workgroup (8 * power of two)
+  size_t off_e, off_we, off_w, lds_bytes;
+  int dbg_skip;        // bit mask of phases to skip (HEP_MBF_SKIP, timing experiments only)
+};
+
 // ---- 3x3 s2 max-pool, TF-SAME with ZERO padding (utils_extra.py:72-86) ----
 struct PoolArgs { const void* in; void* out; int B, H, W, C, Ho, Wo, pad_t, pad_l, bf16; };
 
@@ -100,6 +115,9 @@ void launch_pw(const PwArgs&, hipStream_t);
 void launch_dw(const DwArgs&, hipStream_t);
 void launch_se(const SeArgs&, hipStream_t);
 void launch_pool(const PoolArgs&, hipStream_t);
+void launch_mbf(const MbfArgs&, hipStream_t);
+size_t mbf_lds_layout(int Cin, int CC, int k, int s, int bf16, int has_expand, MbfArgs* a);
+int mbf_prepare(void);
 void launch_sep(const SepArgs&, hipStream_t);
 void launch_decode(const DecodeArgs&, hipStream_t);
 void launch_export(const ExportArgs&, hipStream_t);

@@ -3,6 +3,7 @@
 // liveness-based activation arena.
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -192,7 +193,7 @@ static bool fold_bn(const Pack& pk, const std::string& p, int c, BnFold* out, st
 // index after the plan is complete: each Op records symbolic references here.
 struct Ref { int op; int field; int seg; int idx; size_t woff; int tensor; };
 enum { F_STEM_W, F_STEM_B, F_STEM_OUT, F_PW_A, F_PW_W, F_PW_B, F_PW_SE, F_PW_RES, F_PW_OUT, F_DW_IN, F_DW_W, F_DW_B,
-       F_DW_OUT, F_DW_PART, F_SE_PART, F_SE_WR, F_SE_BR, F_SE_WE, F_SE_BE, F_SE_SCALE, F_POOL_IN, F_POOL_OUT,
+       F_DW_OUT, F_DW_PART, F_MBF_IN, F_MBF_WE, F_MBF_BE, F_MBF_WDW, F_MBF_BDW, F_MBF_OUT, F_MBF_PART, F_SE_PART, F_SE_WR, F_SE_BR, F_SE_WE, F_SE_BE, F_SE_SCALE, F_POOL_IN, F_POOL_OUT,
        F_SEG_SRC, F_SEG_WDW, F_SEG_WPW, F_SEG_BIAS, F_SEG_OUT };
 
 struct Planner {
@@ -220,7 +221,7 @@ struct Planner {
   }
   int new_op(OpKind k, const std::string& name) {
     Op o; memset(&o.stem, 0, sizeof o.stem); memset(&o.pw, 0, sizeof o.pw); memset(&o.dw, 0, sizeof o.dw);
-    memset(&o.se, 0, sizeof o.se); memset(&o.pool, 0, sizeof o.pool); memset(&o.sep, 0, sizeof o.sep);
+    memset(&o.se, 0, sizeof o.se); memset(&o.pool, 0, sizeof o.pool); memset(&o.sep, 0, sizeof o.sep); memset(&o.mbf, 0, sizeof o.mbf);
     o.kind = k; o.name = name;
     s->ops.push_back(o);
     return (int)s->ops.size() - 1;
@@ -280,13 +281,7 @@ struct Planner {
     char nm[64];
     const int inp = x;
     const int Hin = *H, Win = *W;
-    if (b.expand) {
-      snprintf(nm, sizeof nm, "b%d.expand", i);
-      x = add_pw(nm, x, Hin * Win, b.cin, b.cexp, p + "._expand_conv.conv.weight", "", p + "._bn0", ACT_SWISH, -1, -1,
-                 std::string(nm), Hin, Win);
-      if (!ok) return -1;
-    }
-    // depthwise + bn1 + swish (+ SE partial sums)
+    // depthwise geometry
     int pt, pbm, pl, pr; same_pad(Hin, b.k, b.stride, &pt, &pbm); same_pad(Win, b.k, b.stride, &pl, &pr);
     const int Ho = (Hin + b.stride - 1) / b.stride, Wo = (Win + b.stride - 1) / b.stride;
     const PackTensor* wd = get(p + "._depthwise_conv.conv.weight", {b.cexp, 1, b.k, b.k});
@@ -297,22 +292,63 @@ struct Planner {
       for (int t = 0; t < b.k * b.k; t++) wdw[(size_t)t * b.cexp + c] = wd->data[(size_t)c * b.k * b.k + t] * bn1.scale[c];
     snprintf(nm, sizeof nm, "b%d.dw", i);
     const int dw_t = tensor(nm, Ho, Wo, b.cexp);
-    const int TW = Wo >= 32 ? 4 : (Wo >= 16 ? 2 : 1);
-    const int bpi = dw_blocks_per_image(Ho, Wo, b.cexp, TW);
-    snprintf(nm, sizeof nm, "b%d.se_partial", i);
-    const int part_t = tensor(nm, 1, bpi, b.cexp, true);
-    {
+
+    // fused front (expand -> LDS -> depthwise, k_mbf.hip) whenever its LDS tiles fit; the expanded
+    // tensor then never reaches HBM.  HEP_NO_MBF=1 forces the two-kernel path (A/B measurements).
+    int CC = 0;
+    if (!getenv("HEP_NO_MBF"))
+      for (int cand : {64, 32, 16})
+        if (mbf_lds_layout(b.cin, std::min(cand, b.expand ? cand : b.cexp), b.k, b.stride, s->dtype, b.expand, nullptr) <= 159 * 1024) { CC = cand; break; }
+    int part_t, nblk;
+    if (CC) {
+      if (!b.expand) CC = std::min(CC, b.cexp);
+      nblk = ((Ho + 7) / 8) * ((Wo + 7) / 8);
+      snprintf(nm, sizeof nm, "b%d.se_partial", i);
+      part_t = tensor(nm, 1, nblk, b.cexp, true);
+      snprintf(nm, sizeof nm, "b%d.front", i);
+      const int op = new_op(OP_MBF, nm);
+      Op& o = s->ops[op];
+      MbfArgs& m = o.mbf; memset(&m, 0, sizeof m);
+      m.H = Hin; m.W = Win; m.Cin = b.cin; m.Cexp = b.cexp; m.Ho = Ho; m.Wo = Wo; m.k = b.k; m.s = b.stride;
+      m.pad_t = pt; m.pad_l = pl; m.has_expand = b.expand; m.bf16 = s->dtype; m.CC = CC;
+      mbf_lds_layout(b.cin, CC, b.k, b.stride, s->dtype, b.expand, &m);
+      if (b.expand) {
+        const PackTensor* w = get(p + "._expand_conv.conv.weight", {b.cexp, b.cin, 1, 1});
+        BnFold bn0; if (!fold_bn(pk, p + "._bn0", b.cexp, &bn0, err)) ok = false;
+        if (!ok) return -1;
+        const int rows = (b.cexp + 15) / 16 * 16;
+        std::vector<float> wf((size_t)rows * b.cin, 0.f);
+        for (int n = 0; n < b.cexp; n++) for (int k = 0; k < b.cin; k++) wf[(size_t)n * b.cin + k] = w->data[(size_t)n * b.cin + k] * bn0.scale[n];
+        wref(op, F_MBF_WE, wb.put_typed(wf)); wref(op, F_MBF_BE, wb.put_f32(bn0.shift));
+      }
+      wref(op, F_MBF_WDW, wb.put_f32(wdw)); wref(op, F_MBF_BDW, wb.put_f32(bn1.shift));
+      tref(op, F_MBF_IN, x, false); tref(op, F_MBF_OUT, dw_t, true); tref(op, F_MBF_PART, part_t, true);
+      o.act_bytes_per_image = ((double)Hin * Win * b.cin + (double)Ho * Wo * b.cexp) * es();
+      o.weight_bytes = (b.expand ? (double)b.cexp * b.cin * es() : 0.0) + (double)b.k * b.k * b.cexp * 4;
+      o.flops_per_image = (b.expand ? 2.0 * Hin * Win * b.cin * b.cexp : 0.0) + 2.0 * b.k * b.k * Ho * Wo * b.cexp;
+    } else {
+      if (b.expand) {
+        snprintf(nm, sizeof nm, "b%d.expand", i);
+        x = add_pw(nm, x, Hin * Win, b.cin, b.cexp, p + "._expand_conv.conv.weight", "", p + "._bn0", ACT_SWISH, -1, -1,
+                   std::string(nm), Hin, Win);
+        if (!ok) return -1;
+      }
+      const int TW = Wo >= 32 ? 4 : (Wo >= 16 ? 2 : 1);
+      nblk = dw_blocks_per_image(Ho, Wo, b.cexp, TW);
+      snprintf(nm, sizeof nm, "b%d.se_partial", i);
+      part_t = tensor(nm, 1, nblk, b.cexp, true);
       snprintf(nm, sizeof nm, "b%d.dw", i);
       const int op = new_op(OP_DW, nm);
       Op& o = s->ops[op];
       o.dw.H = Hin; o.dw.W = Win; o.dw.C = b.cexp; o.dw.Ho = Ho; o.dw.Wo = Wo; o.dw.k = b.k; o.dw.s = b.stride;
-      o.dw.pad_t = pt; o.dw.pad_l = pl; o.dw.act = ACT_SWISH; o.dw.bf16 = s->dtype; o.dw.TW = TW; o.dw.blocks_per_image = bpi;
+      o.dw.pad_t = pt; o.dw.pad_l = pl; o.dw.act = ACT_SWISH; o.dw.bf16 = s->dtype; o.dw.TW = TW; o.dw.blocks_per_image = nblk;
       wref(op, F_DW_W, wb.put_f32(wdw)); wref(op, F_DW_B, wb.put_f32(bn1.shift));
       tref(op, F_DW_IN, x, false); tref(op, F_DW_OUT, dw_t, true); tref(op, F_DW_PART, part_t, true);
       o.act_bytes_per_image = ((double)Hin * Win + (double)Ho * Wo) * b.cexp * es();
       o.weight_bytes = (double)b.k * b.k * b.cexp * 4;
       o.flops_per_image = 2.0 * b.k * b.k * Ho * Wo * b.cexp;
     }
+    const int bpi = nblk;
     // squeeze-excite FCs
     const PackTensor *wr = get(p + "._se_reduce.conv.weight", {b.se, b.cexp, 1, 1}), *br = get(p + "._se_reduce.conv.bias", {b.se}),
                      *we = get(p + "._se_expand.conv.weight", {b.cexp, b.se, 1, 1}), *be = get(p + "._se_expand.conv.bias", {b.cexp});
@@ -614,6 +650,7 @@ int build_session(Session* s, const Pack& pack, std::string* err) {
   // ---- device allocations ----
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { *err = std::string(#x) + ": " + hipGetErrorString(e_); return HEP_ERR_DEVICE; } } while (0)
   HIPCHK(hipSetDevice(s->device));
+  if (mbf_prepare() != 0) { *err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for mbf_kernel"; return HEP_ERR_DEVICE; }
   if (sep_prepare() != 0) { *err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"; return HEP_ERR_DEVICE; }
   HIPCHK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
   s->weights_bytes = P.wb.host.size();
@@ -656,6 +693,13 @@ int build_session(Session* s, const Pack& pack, std::string* err) {
         case F_DW_B: o.dw.bias = (const float*)ptr; break;
         case F_DW_OUT: o.dw.out = ptr; break;
         case F_DW_PART: o.dw.partial = (float*)ptr; break;
+        case F_MBF_IN: o.mbf.in = ptr; break;
+        case F_MBF_WE: o.mbf.we = ptr; break;
+        case F_MBF_BE: o.mbf.be = (const float*)ptr; break;
+        case F_MBF_WDW: o.mbf.wdw = (const float*)ptr; break;
+        case F_MBF_BDW: o.mbf.bdw = (const float*)ptr; break;
+        case F_MBF_OUT: o.mbf.out = ptr; break;
+        case F_MBF_PART: o.mbf.partial = (float*)ptr; break;
         case F_SE_PART: o.se.partial = (const float*)ptr; break;
         case F_SE_WR: o.se.wr = (const float*)ptr; break;
         case F_SE_BR: o.se.br = (const float*)ptr; break;
