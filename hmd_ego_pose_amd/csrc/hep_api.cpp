@@ -25,7 +25,10 @@ namespace hep {
 
 Session::~Session() {
   for (auto& g : graphs) for (hipGraphExec_t ge : g.second) hipGraphExecDestroy(ge);
-  for (auto& lo : lane_ops) for (Op& o : lo) if (o.kind == OP_SEP) { hipFree((void*)o.sep.segs); hipFree((void*)o.sep.tile_seg); }
+  for (auto& lo : lane_ops) for (Op& o : lo) {
+    if (o.kind == OP_SEP) { hipFree((void*)o.sep.segs); hipFree((void*)o.sep.tile_seg); }
+    if (o.kind == OP_HEAD) { hipFree((void*)o.head.segs); hipFree((void*)o.head.tile_seg); }
+  }
   for (hipStream_t st : lane_streams) hipStreamDestroy(st);
   for (hipEvent_t ev : lane_events) hipEventDestroy(ev);
   if (fork_event) hipEventDestroy(fork_event);
@@ -48,6 +51,7 @@ void launch_op(const Session& s, const Op& op, int batch, hipStream_t st, const 
     case OP_SE: { SeArgs a = op.se; a.B = batch; launch_se(a, st); break; }
     case OP_POOL: { PoolArgs a = op.pool; a.B = batch; launch_pool(a, st); break; }
     case OP_MBF: { MbfArgs a = op.mbf; a.B = batch; launch_mbf(a, st); break; }
+    case OP_HEAD: { HeadArgs a = op.head; a.B = batch; launch_head(a, st); break; }
     case OP_SEP: { SepArgs a = op.sep; a.B = batch; launch_sep(a, st); break; }
   }
 }
@@ -427,6 +431,7 @@ int hep_kernel_symbol(const hep_handle* h, int i, const char** symbol) {
     case OP_SE: snprintf(tmp, sizeof tmp, "se_kernel"); break;
     case OP_POOL: snprintf(tmp, sizeof tmp, "pool_kernel<%s>", t); break;
     case OP_MBF: snprintf(tmp, sizeof tmp, "mbf_kernel<%s, %d, %d>", t, o.mbf.k, o.mbf.s); break;
+    case OP_HEAD: snprintf(tmp, sizeof tmp, "head_kernel<%s>", t); break;
     default: snprintf(tmp, sizeof tmp, "sep_kernel<%s>", t); break;
   }
   buf = tmp; *symbol = buf.c_str();

@@ -21,6 +21,19 @@ __device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + __exp
 __device__ __forceinline__ float apply_act(float x, int act) {
   return act == 1 ? swishf(x) : (act == 2 ? sigmoidf(x) : x);
 }
+// bf16 kernels use v_rcp_f32 (1 ulp) instead of the IEEE division sequence (~10 instructions): the
+// result is rounded to bf16 (8 bits) right after.  The fp32 parity mode keeps the exact division.
+template <bool FAST> __device__ __forceinline__ float swish_t(float x) {
+  const float d = 1.0f + __expf(-x);
+  return FAST ? x * __builtin_amdgcn_rcpf(d) : x / d;
+}
+template <bool FAST> __device__ __forceinline__ float sigmoid_t(float x) {
+  const float d = 1.0f + __expf(-x);
+  return FAST ? __builtin_amdgcn_rcpf(d) : 1.0f / d;
+}
+template <bool FAST> __device__ __forceinline__ float apply_act_t(float x, int act) {
+  return act == 1 ? swish_t<FAST>(x) : (act == 2 ? sigmoid_t<FAST>(x) : x);
+}
 
 // 8 consecutive channels <-> 8 floats
 template <bool BF16> struct Vec8;

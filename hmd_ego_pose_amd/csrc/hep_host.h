@@ -45,11 +45,12 @@ struct TensorDesc {
   void* ext_ptr = nullptr;
 };
 
-enum OpKind { OP_STEM, OP_PW, OP_DW, OP_SE, OP_POOL, OP_SEP, OP_MBF };
+enum OpKind { OP_STEM, OP_PW, OP_DW, OP_SE, OP_POOL, OP_SEP, OP_MBF, OP_HEAD };
 struct Op {
   OpKind kind; std::string name;
-  StemArgs stem; PwArgs pw; DwArgs dw; SeArgs se; PoolArgs pool; SepArgs sep; MbfArgs mbf;
+  StemArgs stem; PwArgs pw; DwArgs dw; SeArgs se; PoolArgs pool; SepArgs sep; MbfArgs mbf; HeadArgs head;
   std::vector<SepSeg> segs;         // host copy (device copy uploaded at build)
+  std::vector<HeadSeg> hsegs;
   std::vector<int> reads, writes;   // tensor ids
   double act_bytes_per_image = 0, flops_per_image = 0, weight_bytes = 0;
 };

@@ -90,6 +90,25 @@ struct SepArgs {
   size_t off_atile, off_wdw, off_bias, lds_bytes;   // LDS layout (k_sep.hip: sep_lds_layout)
 };
 
+// ---- fused heads: D tower layers + header(s) of one (net, level) per workgroup (k_head.hip) ----
+#define HEAD_MAX_DEPTH 5
+struct HeadOut {
+  const float* wdw; const void* wpw; const float* bias;   // header SeparableConv: [9][C], [ceil16(N)][C], [ceil16(N)]
+  float* out;                                             // [B, N_anchors, K] fp32
+  int N, act, col_kin, col_kout, col_off;                 // column n -> (n/kin)*kout + n%kin + off
+  int64_t out_bstride, out_rowstride;                     // floats per image, per anchor cell (9*K)
+};
+struct HeadSeg {
+  const void* feat; int h, w, tiles_x, tile_begin; int64_t out_cell0;     // level map, tiles, first anchor cell of the level
+  const float* wdw[HEAD_MAX_DEPTH]; const void* wpw[HEAD_MAX_DEPTH]; const float* bias[HEAD_MAX_DEPTH];   // tower (per-level BN folded)
+  int nheaders; HeadOut hdr[2];
+};
+struct HeadArgs {
+  const HeadSeg* segs; const int* tile_seg;
+  int nseg, B, total_tiles, bf16, C, depth, ts, chunk;    // ts: tile side; chunk: header columns per pass
+  size_t off_buf1, off_atile, off_wdw, off_bias, lds_bytes;
+};
+
 // ---- decode: boxes + translation from raw heads (loss.py:12-51) ----
 struct DecodeArgs {
   const float* regression; const float* translation_raw; const float* camera;
@@ -119,6 +138,9 @@ void launch_mbf(const MbfArgs&, hipStream_t);
 size_t mbf_lds_layout(int Cin, int CC, int k, int s, int bf16, int has_expand, MbfArgs* a);
 int mbf_prepare(void);
 void launch_sep(const SepArgs&, hipStream_t);
+void launch_head(const HeadArgs&, hipStream_t);
+void head_lds_layout(int C, int depth, int ts, int bf16, int chunk, HeadArgs* a);
+int head_prepare(void);
 void launch_decode(const DecodeArgs&, hipStream_t);
 void launch_export(const ExportArgs&, hipStream_t);
 void launch_filter(const FilterArgs&, hipStream_t);

@@ -194,7 +194,8 @@ static bool fold_bn(const Pack& pk, const std::string& p, int c, BnFold* out, st
 struct Ref { int op; int field; int seg; int idx; size_t woff; int tensor; };
 enum { F_STEM_W, F_STEM_B, F_STEM_OUT, F_PW_A, F_PW_W, F_PW_B, F_PW_SE, F_PW_RES, F_PW_OUT, F_DW_IN, F_DW_W, F_DW_B,
        F_DW_OUT, F_DW_PART, F_MBF_IN, F_MBF_WE, F_MBF_BE, F_MBF_WDW, F_MBF_BDW, F_MBF_OUT, F_MBF_PART, F_SE_PART, F_SE_WR, F_SE_BR, F_SE_WE, F_SE_BE, F_SE_SCALE, F_POOL_IN, F_POOL_OUT,
-       F_SEG_SRC, F_SEG_WDW, F_SEG_WPW, F_SEG_BIAS, F_SEG_OUT };
+       F_SEG_SRC, F_SEG_WDW, F_SEG_WPW, F_SEG_BIAS, F_SEG_OUT,
+       F_HSEG_FEAT, F_HSEG_WDW, F_HSEG_WPW, F_HSEG_BIAS, F_HOUT_WDW, F_HOUT_WPW, F_HOUT_BIAS, F_HOUT_OUT };
 
 struct Planner {
   Session* s; const Pack& pk; std::string* err; WBuilder wb; bool ok = true;
@@ -221,7 +222,7 @@ struct Planner {
   }
   int new_op(OpKind k, const std::string& name) {
     Op o; memset(&o.stem, 0, sizeof o.stem); memset(&o.pw, 0, sizeof o.pw); memset(&o.dw, 0, sizeof o.dw);
-    memset(&o.se, 0, sizeof o.se); memset(&o.pool, 0, sizeof o.pool); memset(&o.sep, 0, sizeof o.sep); memset(&o.mbf, 0, sizeof o.mbf);
+    memset(&o.se, 0, sizeof o.se); memset(&o.pool, 0, sizeof o.pool); memset(&o.sep, 0, sizeof o.sep); memset(&o.mbf, 0, sizeof o.mbf); memset(&o.head, 0, sizeof o.head);
     o.kind = k; o.name = name;
     s->ops.push_back(o);
     return (int)s->ops.size() - 1;
@@ -296,7 +297,13 @@ struct Planner {
     // fused front (expand -> LDS -> depthwise, k_mbf.hip) whenever its LDS tiles fit; the expanded
     // tensor then never reaches HBM.  HEP_NO_MBF=1 forces the two-kernel path (A/B measurements).
     int CC = 0;
-    if (!getenv("HEP_NO_MBF"))
+    // Measured on MI355X at bs16 (profiles/README.md): the fused kernel beats expand+depthwise on
+    // the 32x32 and 16x16 input maps (-30 us per forward) and loses on the big early maps
+    // (bandwidth-bound, the two-kernel path already streams well) and on the 8x8 maps (too few
+    // workgroups per launch).  HEP_MBF=all|none overrides for A/B runs.
+    const char* mode = getenv("HEP_MBF");
+    const bool want = mode ? !strcmp(mode, "all") : (Hin == 16 || Hin == 32);
+    if (want && !(mode && !strcmp(mode, "none")))
       for (int cand : {64, 32, 16})
         if (mbf_lds_layout(b.cin, std::min(cand, b.expand ? cand : b.cexp), b.k, b.stride, s->dtype, b.expand, nullptr) <= 159 * 1024) { CC = cand; break; }
     int part_t, nblk;
@@ -561,44 +568,116 @@ int build_session(Session* s, const Pack& pack, std::string* err) {
   }
   for (int l = 0; l < 5; l++) s->feat_ids[l] = feat[l];
 
-  // ---- heads: D tower layers (5 nets x 5 levels per launch) + one header launch ----
+  // ---- heads ----
   static const char* nets[5] = {"regressor", "classifier", "rotation_net", "translation_net", "hand_net"};
-  int cur[5][5];
-  for (int n = 0; n < 5; n++) for (int l = 0; l < 5; l++) cur[n][l] = feat[l];
-  for (int i = 0; i < A.head_depth; i++) {
-    std::vector<Planner::SegSpec> specs;
+  struct Hd { int net; const char* key; int kin, kout, off, out, act; };
+  static const Hd hds[6] = {{0, "regressor.header", 4, 4, 0, 0, ACT_NONE}, {1, "classifier.header", 1, 1, 0, 1, ACT_SIGMOID},
+                            {2, "rotation_net.initial_rotation", 3, 3, 0, 2, ACT_NONE},
+                            {3, "translation_net.initial_translation_xy", 2, 3, 0, 3, ACT_NONE},
+                            {3, "translation_net.initial_translation_z", 1, 3, 2, 3, ACT_NONE},
+                            {4, "hand_net.initial_hand_coords", 63, 63, 0, 4, ACT_NONE}};
+  // Two implementations: one sepconv launch per tower layer + one for the headers (k_sep.hip), or
+  // ONE launch for all five heads with towers + headers fused per (net, level, tile) and the
+  // intermediate maps in LDS (k_head.hip; needs the two tower maps to fit in LDS).
+  HeadArgs ha; memset(&ha, 0, sizeof ha);
+  ha.C = Wf; ha.depth = A.head_depth; ha.bf16 = s->dtype; ha.chunk = 96;
+  bool fused_heads = false;
+  for (int ts : {8, 4}) {
+    ha.ts = ts; head_lds_layout(Wf, A.head_depth, ts, s->dtype, ha.chunk, &ha);
+    if (ha.lds_bytes <= 159 * 1024 && A.head_depth <= HEAD_MAX_DEPTH) { fused_heads = true; break; }
+  }
+  // Measured on MI355X at bs16: the fused kernel (halo recompute, 1 workgroup per CU) takes 282 us
+  // against 240 us for D+1 per-layer launches, so the per-layer path is the default; HEP_HEAD=fused
+  // selects the fused kernel (kept parity-tested: it wins once launch boundaries get dearer).
+  { const char* e = getenv("HEP_HEAD"); if (!(e && !strcmp(e, "fused"))) fused_heads = false; }
+  if (fused_heads) {
+    const int op = P.new_op(OP_HEAD, "heads.fused");
+    double bytes = 0, flops = 0, wbytes = 0;
+    int tile_begin = 0;
     for (int n = 0; n < 5; n++)
       for (int l = 0; l < 5; l++) {
-        Planner::SegSpec sp;
-        sp.nsrc = 1; sp.src[0] = cur[n][l]; sp.kind[0] = SRC_SAME; sp.fw[0] = 1.f; sp.pre_act = 0; sp.level = l;
-        sp.key = std::string(nets[n]) + ".conv_list." + std::to_string(i);
-        sp.bn = std::string(nets[n]) + ".bn_list." + std::to_string(l) + "." + std::to_string(i);   // per-level BN, shared conv
-        sp.N = Wf; sp.act = ACT_SWISH; sp.head_out = -1; sp.col_kin = sp.col_kout = 1; sp.col_off = 0; sp.out_k = 0;
-        sp.out_t = P.tensor(std::string(nets[n]) + ".t" + std::to_string(i) + ".p" + std::to_string(l + 3), s->levels[l], s->levels[l], Wf);
-        specs.push_back(sp);
+        HeadSeg sg; memset(&sg, 0, sizeof sg);
+        const int hw = s->levels[l], si = n * 5 + l;
+        sg.h = hw; sg.w = hw; sg.tiles_x = (hw + ha.ts - 1) / ha.ts; sg.tile_begin = tile_begin; sg.out_cell0 = s->level_off[l] / 9;
+        tile_begin += sg.tiles_x * sg.tiles_x;
+        s->ops[op].hsegs.push_back(sg);
+        P.tref(op, F_HSEG_FEAT, feat[l], false, si);
+        bytes += (double)hw * hw * Wf * P.es();
+        for (int i = 0; i < A.head_depth; i++) {
+          const std::string key = std::string(nets[n]) + ".conv_list." + std::to_string(i);
+          const PackTensor* wd = P.get(key + ".depthwise_conv.conv.weight", {Wf, 1, 3, 3});
+          const PackTensor* wp = P.get(key + ".pointwise_conv.conv.weight", {Wf, Wf, 1, 1});
+          const PackTensor* bp = P.get(key + ".pointwise_conv.conv.bias", {Wf});
+          BnFold bn; if (!fold_bn(pack, std::string(nets[n]) + ".bn_list." + std::to_string(l) + "." + std::to_string(i), Wf, &bn, err)) P.ok = false;
+          if (!P.ok) return HEP_ERR_PACK;
+          std::vector<float> wdw((size_t)9 * Wf), wf((size_t)Wf * Wf), bf(Wf);
+          for (int c = 0; c < Wf; c++) for (int t = 0; t < 9; t++) wdw[(size_t)t * Wf + c] = wd->data[(size_t)c * 9 + t];
+          for (int o = 0; o < Wf; o++) {
+            for (int k = 0; k < Wf; k++) wf[(size_t)o * Wf + k] = wp->data[(size_t)o * Wf + k] * bn.scale[o];
+            bf[o] = bp->data[o] * bn.scale[o] + bn.shift[o];
+          }
+          P.wref(op, F_HSEG_WDW, P.wb.put_f32(wdw), si, i); P.wref(op, F_HSEG_WPW, P.wb.put_typed(wf), si, i);
+          P.wref(op, F_HSEG_BIAS, P.wb.put_f32(bf), si, i);
+          flops += 2.0 * hw * hw * Wf * (9 + Wf); wbytes += (double)Wf * Wf * P.es() + 10.0 * Wf * 4;
+        }
+        int nh = 0;
+        for (const Hd& h : hds) {
+          if (h.net != n) continue;
+          const int N = 9 * h.kin, rows = (N + 15) / 16 * 16;
+          const PackTensor* wd = P.get(std::string(h.key) + ".depthwise_conv.conv.weight", {Wf, 1, 3, 3});
+          const PackTensor* wp = P.get(std::string(h.key) + ".pointwise_conv.conv.weight", {N, Wf, 1, 1});
+          const PackTensor* bp = P.get(std::string(h.key) + ".pointwise_conv.conv.bias", {N});
+          if (!P.ok) return HEP_ERR_PACK;
+          std::vector<float> wdw((size_t)9 * Wf), wf((size_t)rows * Wf, 0.f), bf(rows, 0.f);
+          for (int c = 0; c < Wf; c++) for (int t = 0; t < 9; t++) wdw[(size_t)t * Wf + c] = wd->data[(size_t)c * 9 + t];
+          for (int o = 0; o < N; o++) { for (int k = 0; k < Wf; k++) wf[(size_t)o * Wf + k] = wp->data[(size_t)o * Wf + k]; bf[o] = bp->data[o]; }
+          HeadOut& ho = s->ops[op].hsegs[si].hdr[nh];
+          ho.N = N; ho.act = h.act; ho.col_kin = h.kin; ho.col_kout = h.kout; ho.col_off = h.off;
+          ho.out_bstride = (int64_t)s->num_anchors * h.kout; ho.out_rowstride = 9 * h.kout;
+          P.wref(op, F_HOUT_WDW, P.wb.put_f32(wdw), si, nh); P.wref(op, F_HOUT_WPW, P.wb.put_typed(wf), si, nh);
+          P.wref(op, F_HOUT_BIAS, P.wb.put_f32(bf), si, nh);
+          P.refs.push_back({op, F_HOUT_OUT, si, nh, 0, -(h.out + 2)});
+          bytes += (double)hw * hw * N * 4; flops += 2.0 * hw * hw * Wf * (9 + N); wbytes += (double)N * Wf * P.es() + 9.0 * Wf * 4;
+          nh++;
+        }
+        s->ops[op].hsegs[si].nheaders = nh;
       }
-    P.add_sep("heads.tower" + std::to_string(i), specs);
-    if (!P.ok) return HEP_ERR_PACK;
-    for (int n = 0; n < 5; n++) for (int l = 0; l < 5; l++) cur[n][l] = specs[n * 5 + l].out_t;
-  }
-  {
-    struct Hd { int net; const char* key; int kin, kout, off, out, act; };
-    static const Hd hds[6] = {{0, "regressor.header", 4, 4, 0, 0, ACT_NONE}, {1, "classifier.header", 1, 1, 0, 1, ACT_SIGMOID},
-                              {2, "rotation_net.initial_rotation", 3, 3, 0, 2, ACT_NONE},
-                              {3, "translation_net.initial_translation_xy", 2, 3, 0, 3, ACT_NONE},
-                              {3, "translation_net.initial_translation_z", 1, 3, 2, 3, ACT_NONE},
-                              {4, "hand_net.initial_hand_coords", 63, 63, 0, 4, ACT_NONE}};
-    std::vector<Planner::SegSpec> specs;
-    for (const Hd& h : hds)
-      for (int l = 0; l < 5; l++) {
-        Planner::SegSpec sp;
-        sp.nsrc = 1; sp.src[0] = cur[h.net][l]; sp.kind[0] = SRC_SAME; sp.fw[0] = 1.f; sp.pre_act = 0; sp.level = l;
-        sp.key = h.key; sp.bn = ""; sp.N = 9 * h.kin; sp.act = h.act; sp.out_t = -1; sp.head_out = h.out;
-        sp.col_kin = h.kin; sp.col_kout = h.kout; sp.col_off = h.off; sp.out_k = h.kout;
-        specs.push_back(sp);
-      }
-    P.add_sep("heads.headers", specs);
-    if (!P.ok) return HEP_ERR_PACK;
+    Op& o = s->ops[op];
+    ha.nseg = 25; ha.total_tiles = tile_begin;
+    o.head = ha; o.act_bytes_per_image = bytes; o.flops_per_image = flops; o.weight_bytes = wbytes;
+  } else {
+    int cur[5][5];
+    for (int n = 0; n < 5; n++) for (int l = 0; l < 5; l++) cur[n][l] = feat[l];
+    for (int i = 0; i < A.head_depth; i++) {
+      std::vector<Planner::SegSpec> specs;
+      for (int n = 0; n < 5; n++)
+        for (int l = 0; l < 5; l++) {
+          Planner::SegSpec sp;
+          sp.nsrc = 1; sp.src[0] = cur[n][l]; sp.kind[0] = SRC_SAME; sp.fw[0] = 1.f; sp.pre_act = 0; sp.level = l;
+          sp.key = std::string(nets[n]) + ".conv_list." + std::to_string(i);
+          sp.bn = std::string(nets[n]) + ".bn_list." + std::to_string(l) + "." + std::to_string(i);   // per-level BN, shared conv
+          sp.N = Wf; sp.act = ACT_SWISH; sp.head_out = -1; sp.col_kin = sp.col_kout = 1; sp.col_off = 0; sp.out_k = 0;
+          sp.out_t = P.tensor(std::string(nets[n]) + ".t" + std::to_string(i) + ".p" + std::to_string(l + 3), s->levels[l], s->levels[l], Wf);
+          specs.push_back(sp);
+        }
+      P.add_sep("heads.tower" + std::to_string(i), specs);
+      if (!P.ok) return HEP_ERR_PACK;
+      for (int n = 0; n < 5; n++) for (int l = 0; l < 5; l++) cur[n][l] = specs[n * 5 + l].out_t;
+    }
+    {
+      std::vector<Planner::SegSpec> specs;
+      for (const Hd& h : hds)
+        for (int l = 0; l < 5; l++) {
+          Planner::SegSpec sp;
+          sp.nsrc = 1; sp.src[0] = cur[h.net][l]; sp.kind[0] = SRC_SAME; sp.fw[0] = 1.f; sp.pre_act = 0; sp.level = l;
+          sp.key = h.key; sp.bn = ""; sp.N = 9 * h.kin; sp.act = h.act; sp.out_t = -1; sp.head_out = h.out;
+          sp.col_kin = h.kin; sp.col_kout = h.kout; sp.col_off = h.off; sp.out_k = h.kout;
+          specs.push_back(sp);
+        }
+      P.add_sep("heads.headers", specs);
+      if (!P.ok) return HEP_ERR_PACK;
+    }
+
   }
 
   // ---- arena layout: first-fit with liveness-based reuse ----
@@ -651,6 +730,7 @@ int build_session(Session* s, const Pack& pack, std::string* err) {
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { *err = std::string(#x) + ": " + hipGetErrorString(e_); return HEP_ERR_DEVICE; } } while (0)
   HIPCHK(hipSetDevice(s->device));
   if (mbf_prepare() != 0) { *err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for mbf_kernel"; return HEP_ERR_DEVICE; }
+  if (head_prepare() != 0) { *err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for head_kernel"; return HEP_ERR_DEVICE; }
   if (sep_prepare() != 0) { *err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"; return HEP_ERR_DEVICE; }
   HIPCHK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
   s->weights_bytes = P.wb.host.size();
@@ -713,6 +793,14 @@ int build_session(Session* s, const Pack& pack, std::string* err) {
         case F_SEG_WPW: o.segs[r.seg].wpw = ptr; break;
         case F_SEG_BIAS: o.segs[r.seg].bias = (const float*)ptr; break;
         case F_SEG_OUT: o.segs[r.seg].out = ptr; break;
+        case F_HSEG_FEAT: o.hsegs[r.seg].feat = ptr; break;
+        case F_HSEG_WDW: o.hsegs[r.seg].wdw[r.idx] = (const float*)ptr; break;
+        case F_HSEG_WPW: o.hsegs[r.seg].wpw[r.idx] = ptr; break;
+        case F_HSEG_BIAS: o.hsegs[r.seg].bias[r.idx] = (const float*)ptr; break;
+        case F_HOUT_WDW: o.hsegs[r.seg].hdr[r.idx].wdw = (const float*)ptr; break;
+        case F_HOUT_WPW: o.hsegs[r.seg].hdr[r.idx].wpw = ptr; break;
+        case F_HOUT_BIAS: o.hsegs[r.seg].hdr[r.idx].bias = (const float*)ptr; break;
+        case F_HOUT_OUT: o.hsegs[r.seg].hdr[r.idx].out = (float*)ptr; break;
       }
     }
     // segment tables to device
@@ -728,6 +816,16 @@ int build_session(Session* s, const Pack& pack, std::string* err) {
         HIPCHK(hipMemcpy(dt, tile_seg.data(), tile_seg.size() * sizeof(int), hipMemcpyHostToDevice));
         o.sep.tile_seg = dt;
         o.sep.seg0 = o.segs[0];
+      } else if (o.kind == OP_HEAD) {
+        HeadSeg* d; HIPCHK(hipMalloc((void**)&d, o.hsegs.size() * sizeof(HeadSeg)));
+        HIPCHK(hipMemcpy(d, o.hsegs.data(), o.hsegs.size() * sizeof(HeadSeg), hipMemcpyHostToDevice));
+        o.head.segs = d;
+        std::vector<int> tile_seg(o.head.total_tiles);
+        for (size_t si = 0; si < o.hsegs.size(); si++)
+          for (int t = 0; t < o.hsegs[si].tiles_x * o.hsegs[si].tiles_x; t++) tile_seg[o.hsegs[si].tile_begin + t] = (int)si;
+        int* dt; HIPCHK(hipMalloc((void**)&dt, tile_seg.size() * sizeof(int)));
+        HIPCHK(hipMemcpy(dt, tile_seg.data(), tile_seg.size() * sizeof(int), hipMemcpyHostToDevice));
+        o.head.tile_seg = dt;
       }
   }
 #undef HIPCHK

@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs a) {
     }
   }
 #pragma unroll
-  for (int c = 0; c < 8; c++) acc[c] = swishf(acc[c]);
+  for (int c = 0; c < 8; c++) acc[c] = swish_t<BF16>(acc[c]);
   Vec8<BF16>::store(a.out, idx * 8, acc);
 }
 
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void dw_kernel(DwArgs a) {
       if (ox0 + p >= a.Wo) continue;
       float v[8];
 #pragma unroll
-      for (int c = 0; c < 8; c++) { v[c] = apply_act(acc[p][c] + bias[c], a.act); sum[c] += v[c]; }
+      for (int c = 0; c < 8; c++) { v[c] = apply_act_t<BF16>(acc[p][c] + bias[c], a.act); sum[c] += v[c]; }
       V::store(a.out, oimg + ((int64_t)oy * a.Wo + ox0 + p) * a.C + cg * 8, v);
     }
   }

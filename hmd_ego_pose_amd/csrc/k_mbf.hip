@@ -138,7 +138,7 @@ __global__ __launch_bounds__(MBF_THREADS) void mbf_kernel(MbfArgs a) {
         const f32x4 bias = *reinterpret_cast<const f32x4*>(be_s + n);
         float v[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) v[q] = inside ? swishf(acc[q] + bias[q]) : 0.f;
+        for (int q = 0; q < 4; q++) v[q] = inside ? swish_t<BF16>(acc[q] + bias[q]) : 0.f;
         V::store4(e_s, (int64_t)m * EP + n, v);
       }
       acc = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(MBF_THREADS) void mbf_kernel(MbfArgs a) {
       if (oy < a.Ho && ox < a.Wo) {
         float v[8];
 #pragma unroll
-        for (int c = 0; c < 8; c++) { v[c] = swishf(acc[c]); sum[c] += v[c]; }
+        for (int c = 0; c < 8; c++) { v[c] = swish_t<BF16>(acc[c]); sum[c] += v[c]; }
         V::store(a.out, (((int64_t)b * a.Ho + oy) * a.Wo + ox) * a.Cexp + c0 + cg * 8, v);
       }
     }

@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
       if (!mok[i]) continue;
       float v[4];
 #pragma unroll
-      for (int q = 0; q < 4; q++) v[q] = apply_act(acc[i][j][q] + b[q], a.act);
+      for (int q = 0; q < 4; q++) v[q] = apply_act_t<BF16>(acc[i][j][q] + b[q], a.act);
       const int64_t o = (int64_t)mrow[i] * a.N + n;
       if (R) {
         float rr[4]; V::load4(R, o, rr);

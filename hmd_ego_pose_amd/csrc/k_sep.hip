@@ -102,7 +102,7 @@ __device__ __forceinline__ void gather_fuse(const SepSeg& sg, int b, int y, int 
   }
   if (sg.pre_act) {
 #pragma unroll
-    for (int c = 0; c < 8; c++) v[c] = swishf(v[c]);
+    for (int c = 0; c < 8; c++) v[c] = swish_t<BF16>(v[c]);
   }
 }
 
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(SEP_THREADS_OF(SINGLE), 4) void sep_kernel(SepArgs 
       const f32x4 bias = *reinterpret_cast<const f32x4*>(bias_s + n);
       float v[4];
 #pragma unroll
-      for (int q = 0; q < 4; q++) v[q] = apply_act(acc[q] + bias[q], sg.act);
+      for (int q = 0; q < 4; q++) v[q] = apply_act_t<BF16>(acc[q] + bias[q], sg.act);
       if (sg.out_f32) {
 #pragma unroll
         for (int q = 0; q < 4; q++) if (n + q < Nc) otile_f[(int64_t)m * Nc + n + q] = v[q];
