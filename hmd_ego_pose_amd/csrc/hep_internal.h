@@ -88,6 +88,7 @@ struct SepArgs {
   SepSeg seg0;                               // the only segment of a single-segment launch (kernel argument)
   int nseg; int B; int total_tiles; int bf16; int C;
   size_t off_atile, off_wdw, off_bias, lds_bytes;   // LDS layout (k_sep.hip: sep_lds_layout)
+  int dbg_skip;                              // HEP_SEP_SKIP phase mask (timing experiments only)
 };
 
 // ---- fused heads: D tower layers + header(s) of one (net, level) per workgroup (k_head.hip) ----

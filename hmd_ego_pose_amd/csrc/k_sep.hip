@@ -24,6 +24,8 @@
 //            LDS output tile (over the dead halo)
 //   phase 4  the output tile leaves as full coalesced rows.  Head outputs land directly at their
 //            anchor offset in the [B, N_anchors, K] result (no permute / cat pass).
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "hep_dev.h"
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(SEP_THREADS_OF(SINGLE), 4) void sep_kernel(SepArgs 
   for (int i = threadIdx.x; i < sg.tilesN * 16; i += SEP_THREADS) bias_s[i] = sg.bias[i];
 
   // ---- phase 1: fused (+swish) halo of the depthwise input, zero outside the image ----
-  for (int item = threadIdx.x; item < HS * HS * CG; item += SEP_THREADS) {
+  for (int item = threadIdx.x; item < ((a.dbg_skip & 1) ? 0 : HS * HS * CG); item += SEP_THREADS) {
     const int pos = item / CG, cg = item % CG;
     const int y = y0 + pos / HS - 1, x = x0 + pos % HS - 1;
     float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(SEP_THREADS_OF(SINGLE), 4) void sep_kernel(SepArgs 
   __syncthreads();
 
   // ---- phase 2: depthwise 3x3 -> operand tile [TS*TS pixels][C] ----
-  for (int item = threadIdx.x; item < TS * TS * CG; item += SEP_THREADS) {
+  for (int item = threadIdx.x; item < ((a.dbg_skip & 2) ? 0 : TS * TS * CG); item += SEP_THREADS) {
     const int p = item / CG, cg = item % CG;
     const int py = p / TS, px = p % TS;
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -222,7 +224,7 @@ __global__ __launch_bounds__(SEP_THREADS_OF(SINGLE), 4) void sep_kernel(SepArgs 
     }
     acc = (f32x4){0.f, 0.f, 0.f, 0.f};
   };
-  for (int it = 0; it < my_items; it += 4) {
+  for (int it = 0; it < ((a.dbg_skip & 4) ? 0 : my_items); it += 4) {
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       if (it + q < my_items) {
@@ -235,6 +237,7 @@ __global__ __launch_bounds__(SEP_THREADS_OF(SINGLE), 4) void sep_kernel(SepArgs 
   __syncthreads();
 
   // ---- phase 4: coalesced copy-out ----
+  if (a.dbg_skip & 8) return;
   if (sg.out_f32) {
     // head result [B, N_anchors, K]: pixel p owns 9*K consecutive floats; this segment's Nc columns
     float* o = reinterpret_cast<float*>(sg.out) + (int64_t)b * sg.out_bstride + sg.out_off;
@@ -249,21 +252,17 @@ __global__ __launch_bounds__(SEP_THREADS_OF(SINGLE), 4) void sep_kernel(SepArgs 
       }
     }
   } else {
-    // NHWC map: a tile row of cols_valid pixels x Nc channels is one contiguous run
+    // NHWC map (possibly a column chunk [out_off, out_off+Nc) of a wider map): consecutive lanes
+    // write consecutive 16-byte vectors of a pixel, then the next pixel of the tile row
     T* o = reinterpret_cast<T*>(sg.out) + (int64_t)b * sg.out_bstride + sg.out_off;
-    const int vec_per_row = TS * Nc / 8, vec_valid = cols_valid * Nc / 8;
-    for (int idx = threadIdx.x; idx < rows_valid * vec_per_row; idx += SEP_THREADS) {
-      const int py = idx / vec_per_row, v = idx % vec_per_row;
-      if (v >= vec_valid) continue;
-      const u32x4 val = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(otile_t) + ((int64_t)py * TS * Nc + v * 8) * sizeof(T));
-      const int64_t dst = ((int64_t)(y0 + py) * w + x0) * Nc + v * 8;
-      if constexpr (BF16) {
-        *reinterpret_cast<u32x4*>(o + dst) = val;
-      } else {    // fp32: 8 elements = two 16-byte vectors
-        const u32x4 val2 = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(otile_t) + ((int64_t)py * TS * Nc + v * 8) * sizeof(T) + 16);
-        *reinterpret_cast<u32x4*>(o + dst) = val;
-        *reinterpret_cast<u32x4*>(o + dst + 4) = val2;
-      }
+    const int vpp = Nc >> 3;
+    for (int idx = threadIdx.x; idx < rows_valid * cols_valid * vpp; idx += SEP_THREADS) {
+      const int pix = idx / vpp, cv = idx % vpp;
+      const int py = pix / cols_valid, px = pix % cols_valid;
+      const unsigned char* src = reinterpret_cast<const unsigned char*>(otile_t) + ((int64_t)(py * TS + px) * Nc + cv * 8) * sizeof(T);
+      T* dst = o + ((int64_t)(y0 + py) * w + x0 + px) * sg.out_rowstride + cv * 8;
+      *reinterpret_cast<u32x4*>(dst) = *reinterpret_cast<const u32x4*>(src);
+      if constexpr (!BF16) *reinterpret_cast<u32x4*>(dst + 4) = *reinterpret_cast<const u32x4*>(src + 16);
     }
   }
 }
@@ -289,7 +288,10 @@ int sep_prepare(void) {
   return 0;
 }
 
-void launch_sep(const SepArgs& a, hipStream_t s) {
+void launch_sep(const SepArgs& a_, hipStream_t s) {
+  SepArgs a = a_;
+  static const int skip = getenv("HEP_SEP_SKIP") ? atoi(getenv("HEP_SEP_SKIP")) : 0;   // timing experiments only (results are wrong)
+  a.dbg_skip = skip;
   dim3 grid(a.total_tiles, a.B);
   if (a.bf16) {
     if (a.nseg == 1) hipLaunchKernelGGL((sep_kernel<true, true>), grid, dim3(SEP_THREADS_OF(true)), a.lds_bytes, s, a);

@@ -192,3 +192,24 @@ def test_module_dropin_and_pipeline(api):
     sel = D.filter_detections(gb[1].cpu().numpy(), cls[1].cpu().numpy(), rot[1].cpu().numpy(), gt[1].cpu().numpy(), hand[1].cpu().numpy())
     for got, want in zip(out, sel[:6]):
         assert np.array_equal(got.numpy(), want)
+
+
+@pytest.mark.parametrize("env", [{"HEP_MBF": "all"}, {"HEP_MBF": "none"}, {"HEP_HEAD": "fused"}, {"HEP_LANES": "2"}])
+def test_alternative_plans_keep_parity(api, env, monkeypatch):
+    """The planner picks between implementations by measurement (fused MBConv front vs expand+depthwise,
+    fused heads vs per-layer, batch lanes); every alternative must produce the same numbers."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    phi, size, batch = 0, 256, 3
+    sd = api["sd"](phi, 4)
+    x = torch.from_numpy(seeded_input((batch, 3, size, size), 21))
+    ref = api["R"].forward(sd, x, phi)
+    s = api["Session"](sd, phi, size, batch, "fp32")
+    out = s.forward(x.cuda())
+    torch.cuda.synchronize()
+    for name, a, b in zip(("regression", "classification", "rotation", "translation_raw", "hand"), out[1:], ref[1:]):
+        err = (a.cpu() - b).abs().max().item()
+        assert err <= 1e-3, f"{env} {name}: {err:.3e}"
+    for a, b in zip(out[0], ref[0]):
+        assert (a.cpu() - b).abs().max().item() <= 1e-3
+    s.close()
