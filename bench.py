@@ -49,6 +49,17 @@ def cpu_baseline(phi, size, budget_s=15.0):
         D.decode_boxes(anchors, reg.numpy(), size)
         D.decode_translation(t_anchors, trn.numpy(), cam)
 
+    # the box has far more CPUs than these small convolutions can use: take the fastest thread count
+    best = None
+    for nt in (8, 16, 32, 64, 128):
+        if nt > (os.cpu_count() or 1):
+            break
+        torch.set_num_threads(nt)
+        one()
+        t0 = time.perf_counter(); one(); one(); dt = time.perf_counter() - t0
+        if best is None or dt < best[0]:
+            best = (dt, nt)
+    torch.set_num_threads(best[1])
     for _ in range(3):
         one()
     n, t0 = 0, time.perf_counter()
@@ -59,7 +70,7 @@ def cpu_baseline(phi, size, budget_s=15.0):
             break
     return {"value": round(n / el, 3), "unit": "frames/s", "cores": int(torch.get_num_threads()), "kind": "port",
             "sample": f"{n} frames, batch 1 per call (evaluate.py regime), phi {phi} {size}x{size} fp32, "
-                      f"forward + anchors + box/translation decode, {el:.1f} s on {os.cpu_count()} host CPUs"}
+                      f"forward + anchors + box/translation decode, {el:.1f} s, best of 8..128 torch threads on {os.cpu_count()} host CPUs"}
 
 
 def main():
@@ -143,7 +154,7 @@ def main():
                                "kernel": sym, "launches_per_step": calls, "avg_launch_us": round(t / calls * 1e3, 2),
                                "algorithmic_bytes_per_launch": round(nbytes / calls), "share_of_step": round(t / sum(per), 3),
                                "graph_replay_ms": round(total_ms, 4),
-                               "end_to_end_frac": round(sum(k[1] for k in ks) / (total_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                               "end_to_end_frac": round(sum(k[1] for k in ks) * -(-B // max(1, min(B, sess.lane_batch))) / (total_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(phi, S)
         print(json.dumps(out), flush=True)

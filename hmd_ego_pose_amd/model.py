@@ -14,6 +14,7 @@ library raise - the reference's training graph is out of scope for this build.
 from __future__ import annotations
 
 import ctypes
+import os
 import threading
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -50,6 +51,10 @@ class Session:
                                                        self.device.index or 0, flags, ctypes.byref(h)))
         self.handle = h.value
         self.num_anchors = _capi.lib().hep_num_anchors(self.handle)
+        self.lane_batch = max_batch      # frames per launch (the batch is one lane unless HEP_LANES says otherwise)
+        if os.environ.get("HEP_LANES"):
+            lanes = max(1, min(int(os.environ["HEP_LANES"]), max_batch, 16))
+            self.lane_batch = -(-max_batch // lanes)
         self.fpn_w = get_arch(phi).fpn_w
         self.levels = level_sizes(size)
         with Session._lock:
