@@ -264,6 +264,8 @@ struct Planner {
       } else {                      // small maps, wide N (expand / lateral): waves side by side in N
         o.pw.mode = 1; o.pw.MT = 1; o.pw.NT = clampi(strips * tilesN / (4 * 256), 1, std::min(8, (tilesN + 3) / 4));
       }
+      // (measured and rejected on MI355X: two m-tiles per wave in modes 1/2 to halve the W re-reads from
+      //  L2, and a 3-deep fragment ring - neither moved these layers, they sit ~3 us above an empty launch)
     }
     wref(op, F_PW_W, wb.put_typed(wf)); wref(op, F_PW_B, wb.put_f32(bf));
     tref(op, F_PW_A, in_t, false); tref(op, F_PW_OUT, out_t, true);
@@ -340,21 +342,45 @@ struct Planner {
                    std::string(nm), Hin, Win);
         if (!ok) return -1;
       }
-      const int TW = Wo >= 32 ? 4 : (Wo >= 16 ? 2 : 1);
-      nblk = dw_blocks_per_image(Ho, Wo, b.cexp, TW);
-      snprintf(nm, sizeof nm, "b%d.se_partial", i);
-      part_t = tensor(nm, 1, nblk, b.cexp, true);
-      snprintf(nm, sizeof nm, "b%d.dw", i);
-      const int op = new_op(OP_DW, nm);
-      Op& o = s->ops[op];
-      o.dw.H = Hin; o.dw.W = Win; o.dw.C = b.cexp; o.dw.Ho = Ho; o.dw.Wo = Wo; o.dw.k = b.k; o.dw.s = b.stride;
-      o.dw.pad_t = pt; o.dw.pad_l = pl; o.dw.act = ACT_SWISH; o.dw.bf16 = s->dtype; o.dw.TW = TW; o.dw.blocks_per_image = nblk;
-      wref(op, F_DW_W, wb.put_f32(wdw)); wref(op, F_DW_B, wb.put_f32(bn1.shift));
-      tref(op, F_DW_IN, x, false); tref(op, F_DW_OUT, dw_t, true); tref(op, F_DW_PART, part_t, true);
-      o.act_bytes_per_image = ((double)Hin * Win + (double)Ho * Wo) * b.cexp * es();
-      o.weight_bytes = (double)b.k * b.k * b.cexp * 4;
-      o.flops_per_image = 2.0 * b.k * b.k * Ho * Wo * b.cexp;
-    }
+      // depthwise on its own: from global memory for the big maps (bandwidth-bound, k_dw.hip), through
+      // LDS (the fused kernel without its expand stage) on the 8x8 maps, where the global-memory
+      // version is a chain of k*k dependent load latencies.  HEP_DWLDS=0|1 overrides.
+      const char* dl = getenv("HEP_DWLDS");
+      const bool lds_dw = dl ? atoi(dl) != 0 : (Hin <= 8);
+      const int ccl = std::min(64, b.cexp);
+      if (lds_dw && mbf_lds_layout(b.cexp, ccl, b.k, b.stride, s->dtype, 0, nullptr) <= 159 * 1024) {
+        nblk = ((Ho + 7) / 8) * ((Wo + 7) / 8);
+        snprintf(nm, sizeof nm, "b%d.se_partial", i);
+        part_t = tensor(nm, 1, nblk, b.cexp, true);
+        snprintf(nm, sizeof nm, "b%d.dw", i);
+        const int op = new_op(OP_MBF, nm);
+        Op& o = s->ops[op];
+        MbfArgs& m = o.mbf; memset(&m, 0, sizeof m);
+        m.H = Hin; m.W = Win; m.Cin = b.cexp; m.Cexp = b.cexp; m.Ho = Ho; m.Wo = Wo; m.k = b.k; m.s = b.stride;
+        m.pad_t = pt; m.pad_l = pl; m.has_expand = 0; m.bf16 = s->dtype; m.CC = ccl;
+        mbf_lds_layout(b.cexp, ccl, b.k, b.stride, s->dtype, 0, &m);
+        wref(op, F_MBF_WDW, wb.put_f32(wdw)); wref(op, F_MBF_BDW, wb.put_f32(bn1.shift));
+        tref(op, F_MBF_IN, x, false); tref(op, F_MBF_OUT, dw_t, true); tref(op, F_MBF_PART, part_t, true);
+        o.act_bytes_per_image = ((double)Hin * Win + (double)Ho * Wo) * b.cexp * es();
+        o.weight_bytes = (double)b.k * b.k * b.cexp * 4;
+        o.flops_per_image = 2.0 * b.k * b.k * Ho * Wo * b.cexp;
+      } else {
+        const int TW = Wo >= 32 ? 4 : (Wo >= 16 ? 2 : 1);
+        nblk = dw_blocks_per_image(Ho, Wo, b.cexp, TW);
+        snprintf(nm, sizeof nm, "b%d.se_partial", i);
+        part_t = tensor(nm, 1, nblk, b.cexp, true);
+        snprintf(nm, sizeof nm, "b%d.dw", i);
+        const int op = new_op(OP_DW, nm);
+        Op& o = s->ops[op];
+        o.dw.H = Hin; o.dw.W = Win; o.dw.C = b.cexp; o.dw.Ho = Ho; o.dw.Wo = Wo; o.dw.k = b.k; o.dw.s = b.stride;
+        o.dw.pad_t = pt; o.dw.pad_l = pl; o.dw.act = ACT_SWISH; o.dw.bf16 = s->dtype; o.dw.TW = TW; o.dw.blocks_per_image = nblk;
+        wref(op, F_DW_W, wb.put_f32(wdw)); wref(op, F_DW_B, wb.put_f32(bn1.shift));
+        tref(op, F_DW_IN, x, false); tref(op, F_DW_OUT, dw_t, true); tref(op, F_DW_PART, part_t, true);
+        o.act_bytes_per_image = ((double)Hin * Win + (double)Ho * Wo) * b.cexp * es();
+        o.weight_bytes = (double)b.k * b.k * b.cexp * 4;
+        o.flops_per_image = 2.0 * b.k * b.k * Ho * Wo * b.cexp;
+      }
+      }
     const int bpi = nblk;
     // squeeze-excite FCs
     const PackTensor *wr = get(p + "._se_reduce.conv.weight", {b.se, b.cexp, 1, 1}), *br = get(p + "._se_reduce.conv.bias", {b.se}),

@@ -202,30 +202,48 @@ __global__ __launch_bounds__(SE_THREADS) void se_kernel(SeArgs a) {
     mean[c] = ((s0 + s1) + (s2 + s3)) * a.inv_hw;
   }
   __syncthreads();
+  // reduce FC: wave w owns rows w, w+16, w+32 (sq <= 48 on every EfficientNet up to B7: rows beyond
+  // that loop again); the loads of all its rows are issued before the first is consumed
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int j = wave; j < a.sq; j += SE_THREADS / 64) {
-    const float* wr = a.wr + (int64_t)j * a.C;
-    float s = 0.f;
+  constexpr int NW = SE_THREADS / 64;
+  for (int j0 = wave; j0 < a.sq; j0 += 3 * NW) {
+    float s[3] = {0.f, 0.f, 0.f};
     for (int c = lane * 4; c < a.C; c += 256) {   // C is a multiple of 8
-      const f32x4 w = *reinterpret_cast<const f32x4*>(wr + c);
-      s += w[0] * mean[c] + w[1] * mean[c + 1] + w[2] * mean[c + 2] + w[3] * mean[c + 3];
+      f32x4 w[3];
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+        const int j = j0 + q * NW;
+        w[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (j < a.sq) w[q] = *reinterpret_cast<const f32x4*>(a.wr + (int64_t)j * a.C + c);
+      }
+      const f32x4 m = *reinterpret_cast<const f32x4*>(mean + c);
+#pragma unroll
+      for (int q = 0; q < 3; q++) s[q] += w[q][0] * m[0] + w[q][1] * m[1] + w[q][2] * m[2] + w[q][3] * m[3];
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    if (lane == 0) hid[j] = swishf(s + a.br[j]);
+    for (int q = 0; q < 3; q++) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) s[q] += __shfl_xor(s[q], o);
+      const int j = j0 + q * NW;
+      if (lane == 0 && j < a.sq) hid[j] = swishf(s[q] + a.br[j]);
+    }
   }
   __syncthreads();
+  // expand FC: 8 coalesced row loads in flight per lane
   const int per = (a.C + SE_SPLIT - 1) / SE_SPLIT;
   const int c0 = blockIdx.y * per, c1 = min(a.C, c0 + per);
   for (int c = c0 + threadIdx.x; c < c1; c += SE_THREADS) {
-    float s0 = a.be[c], s1 = 0.f;
+    float acc[4] = {a.be[c], 0.f, 0.f, 0.f};
     int j = 0;
-    for (; j + 2 <= a.sq; j += 2) {
-      s0 = fmaf(a.we[(int64_t)j * a.C + c], hid[j], s0);
-      s1 = fmaf(a.we[(int64_t)(j + 1) * a.C + c], hid[j + 1], s1);
+    for (; j + 8 <= a.sq; j += 8) {
+      float w[8];
+#pragma unroll
+      for (int q = 0; q < 8; q++) w[q] = a.we[(int64_t)(j + q) * a.C + c];
+#pragma unroll
+      for (int q = 0; q < 8; q++) acc[q & 3] = fmaf(w[q], hid[j + q], acc[q & 3]);
     }
-    if (j < a.sq) s0 = fmaf(a.we[(int64_t)j * a.C + c], hid[j], s0);
-    a.scale[(int64_t)b * a.C + c] = sigmoidf(s0 + s1);
+    for (; j < a.sq; j++) acc[0] = fmaf(a.we[(int64_t)j * a.C + c], hid[j], acc[0]);
+    a.scale[(int64_t)b * a.C + c] = sigmoidf((acc[0] + acc[1]) + (acc[2] + acc[3]));
   }
 }
 void launch_se(const SeArgs& a, hipStream_t s) {
