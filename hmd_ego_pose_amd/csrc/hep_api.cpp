@@ -432,7 +432,7 @@ int hep_kernel_symbol(const hep_handle* h, int i, const char** symbol) {
     case OP_POOL: snprintf(tmp, sizeof tmp, "pool_kernel<%s>", t); break;
     case OP_MBF: snprintf(tmp, sizeof tmp, "mbf_kernel<%s, %d, %d>", t, o.mbf.k, o.mbf.s); break;
     case OP_HEAD: snprintf(tmp, sizeof tmp, "head_kernel<%s>", t); break;
-    default: snprintf(tmp, sizeof tmp, "sep_kernel<%s, %s>", t, o.sep.nseg == 1 ? "true" : "false"); break;
+    default: snprintf(tmp, sizeof tmp, "sep_kernel<%s, %d>", t, o.sep.chain ? 2 : (o.sep.nseg == 1 ? 0 : 1)); break;
   }
   buf = tmp; *symbol = buf.c_str();
   return 0;

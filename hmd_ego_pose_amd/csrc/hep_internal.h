@@ -87,6 +87,7 @@ struct SepArgs {
   const SepSeg* segs; const int* tile_seg;   // device tables: segments, and tile (blockIdx.x) -> segment
   SepSeg seg0;                               // the only segment of a single-segment launch (kernel argument)
   int nseg; int B; int total_tiles; int bf16; int C;
+  int chain;                                 // segments are a dependency chain run by one workgroup per image
   size_t off_atile, off_wdw, off_bias, lds_bytes;   // LDS layout (k_sep.hip: sep_lds_layout)
   int dbg_skip;                              // HEP_SEP_SKIP phase mask (timing experiments only)
 };

@@ -422,7 +422,7 @@ struct Planner {
     int out_t;                       // dtype tensor, or -1 for a head output
     int head_out; int col_kin, col_kout, col_off, out_k;   // head output index 0..4 and column mapping
   };
-  void add_sep(const std::string& name, const std::vector<SegSpec>& specs) {
+  void add_sep(const std::string& name, const std::vector<SegSpec>& specs, bool chain = false) {
     const int C = s->arch.fpn_w;
     const int op = new_op(OP_SEP, name);
     int tile_begin = 0, ts_max = 8, cols_f32 = 0, cols_map = 0;
@@ -482,6 +482,7 @@ struct Planner {
     }
     Op& o = s->ops[op];
     o.sep.nseg = (int)o.segs.size(); o.sep.total_tiles = tile_begin; o.sep.bf16 = s->dtype; o.sep.C = C;
+    o.sep.chain = chain && o.segs.size() > 1;
     sep_lds_layout(C, s->dtype, ts_max, cols_f32, cols_map, &o.sep);
     if (o.sep.lds_bytes > 160 * 1024) { *err = "BiFPN width too large for the fused separable-conv tile"; ok = false; return; }
     o.act_bytes_per_image = bytes; o.flops_per_image = flops; o.weight_bytes = wbytes;
@@ -536,6 +537,7 @@ int build_session(Session* s, const Pack& pack, std::string* err) {
   // ---- BiFPN ----
   const int Wf = A.fpn_w;
   int feat[5];
+  std::vector<Planner::SegSpec> pending; std::vector<std::string> pending_names;   // small-level BiFPN nodes awaiting a chain launch
   for (int r = 0; r < A.fpn_cells; r++) {
     const std::string p = "bifpn." + std::to_string(r);
     const std::string tn = "c" + std::to_string(r) + ".";
@@ -572,6 +574,18 @@ int build_session(Session* s, const Pack& pack, std::string* err) {
       for (int l = 0; l < 5; l++) { in[l] = feat[l]; in2[l] = feat[l]; }
     }
     float w[3];
+    // Consecutive nodes on levels <= 8x8 (one tile per image) can be launched as ONE chain: a workgroup
+    // per image runs them back to back (k_sep.hip mode 2).
+    // Measured: a 5-node chain takes 44 us, the same as five launches (each node is ~8 us of serialized
+    // global round trips with or without a kernel boundary), so chains are OFF by default (HEP_CHAIN=1).
+    static const bool chain_on = getenv("HEP_CHAIN") && atoi(getenv("HEP_CHAIN")) != 0;
+    auto flush = [&]() {
+      if (pending.empty()) return;
+      std::string nm = pending_names.front();
+      for (size_t i = 1; i < pending_names.size(); i++) nm += "+" + pending_names[i].substr(pending_names[i].find('.') + 1);
+      P.add_sep(nm, pending, pending.size() > 1);
+      pending.clear(); pending_names.clear();
+    };
     auto node = [&](const char* conv, const char* wkey, int nw, int level, std::vector<std::pair<int, int>> srcs, const std::string& oname) {
       fusion_weights(pack, p + "." + wkey, nw, A.attention, w, &P.ok, err);
       Planner::SegSpec sp;
@@ -579,7 +593,8 @@ int build_session(Session* s, const Pack& pack, std::string* err) {
       sp.N = Wf; sp.act = ACT_NONE; sp.head_out = -1; sp.col_kin = sp.col_kout = 1; sp.col_off = 0; sp.out_k = 0;
       for (int j = 0; j < sp.nsrc; j++) { sp.src[j] = srcs[j].first; sp.kind[j] = srcs[j].second; sp.fw[j] = w[j]; }
       sp.out_t = P.tensor(oname, s->levels[level], s->levels[level], Wf);
-      P.add_sep(tn + conv, {sp});
+      if (chain_on && s->levels[level] <= 8 && Wf <= SEP_MAX_TILES_N * 16) { pending.push_back(sp); pending_names.push_back(tn + conv); }
+      else { flush(); P.add_sep(tn + conv, {sp}); }
       return sp.out_t;
     };
     const int p6_up = node("conv6_up", "p6_w1", 2, 3, {{in[3], SRC_SAME}, {in[4], SRC_UP}}, tn + "p6_up"); if (!P.ok) return HEP_ERR_PACK;
@@ -592,6 +607,13 @@ int build_session(Session* s, const Pack& pack, std::string* err) {
     const int p7_out = node("conv7_down", "p7_w2", 2, 4, {{in[4], SRC_SAME}, {p6_out, SRC_DOWN}}, tn + "p7_out"); if (!P.ok) return HEP_ERR_PACK;
     feat[0] = p3_out; feat[1] = p4_out; feat[2] = p5_out; feat[3] = p6_out; feat[4] = p7_out;
   }
+  if (!pending.empty()) {
+    std::string nm = pending_names.front();
+    for (size_t i = 1; i < pending_names.size(); i++) nm += "+" + pending_names[i].substr(pending_names[i].find('.') + 1);
+    P.add_sep(nm, pending, pending.size() > 1);
+    pending.clear(); pending_names.clear();
+  }
+  if (!P.ok) return HEP_ERR_PACK;
   for (int l = 0; l < 5; l++) s->feat_ids[l] = feat[l];
 
   // ---- heads ----

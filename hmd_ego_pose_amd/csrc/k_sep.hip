@@ -31,9 +31,18 @@
 #include "hep_dev.h"
 #include "hep_internal.h"
 
-// BiFPN nodes (single segment, <= 256 workgroups, pure latency): 16 waves per workgroup.
-// Head layers (25-40 segments, ~2000 workgroups, throughput): 8 waves so two workgroups share a CU.
-#define SEP_THREADS_OF(single) ((single) ? 1024 : 512)
+// Launch modes:
+//   0  one segment, descriptor in the kernel arguments            (BiFPN node on a 16x16 / 32x32 level)
+//   1  many independent segments, tile -> segment table            (a tower layer / the headers of all heads)
+//   2  a CHAIN of dependent single-tile segments run back to back by one workgroup per image
+//      (consecutive BiFPN nodes on levels <= 8x8: p5_out -> p6_out -> p7_out -> p6_up' -> p5_up'):
+//      the dependency is carried by a workgroup barrier instead of 4 kernel boundaries
+// Modes 0/2 (<= 256 workgroups, pure latency): 16 waves per workgroup.  Mode 1 (~2000 workgroups,
+// throughput): 8 waves so two workgroups share a CU.
+#define SEP_THREADS_OF(mode) ((mode) != 1 ? 1024 : 512)
+#ifndef SEP_M1_WAVES
+#define SEP_M1_WAVES 4
+#endif
 
 // 8 channels as loaded (bf16: one 16-byte vector = 4 VGPRs; fp32: two)
 template <bool BF16> struct Raw8;
@@ -108,9 +117,10 @@ __device__ __forceinline__ void gather_fuse(const SepSeg& sg, int b, int y, int 
   }
 }
 
-template <bool BF16, bool SINGLE>
-__global__ __launch_bounds__(SEP_THREADS_OF(SINGLE), 4) void sep_kernel(SepArgs a) {
-  constexpr int SEP_THREADS = SEP_THREADS_OF(SINGLE), SEP_WAVES = SEP_THREADS / 64;
+template <bool BF16, int MODE>
+__global__ __launch_bounds__(SEP_THREADS_OF(MODE), MODE == 1 ? SEP_M1_WAVES : 4) void sep_kernel(SepArgs a) {
+  constexpr int SEP_THREADS = SEP_THREADS_OF(MODE), SEP_WAVES = SEP_THREADS / 64;
+  constexpr bool SINGLE = MODE == 0;
   typedef Vec8<BF16> V;
   typedef typename V::elem T;
   typedef typename std::conditional<BF16, u32x4, f32x4>::type raw_t;
@@ -120,15 +130,16 @@ __global__ __launch_bounds__(SEP_THREADS_OF(SINGLE), 4) void sep_kernel(SepArgs 
   // nodes) take it from the kernel arguments (scalar loads), multi-segment launches (heads) copy
   // theirs into LDS once
   __shared__ SepSeg seg_s;
+  for (int chain_i = 0; chain_i < (MODE == 2 ? a.nseg : 1); chain_i++) {
   if (!SINGLE) {
-    const int si = a.tile_seg[blockIdx.x];
+    const int si = MODE == 2 ? chain_i : a.tile_seg[blockIdx.x];
     const uint32_t* src = reinterpret_cast<const uint32_t*>(a.segs + si);
     if (threadIdx.x < sizeof(SepSeg) / 4) reinterpret_cast<uint32_t*>(&seg_s)[threadIdx.x] = src[threadIdx.x];
     __syncthreads();
   }
   const SepSeg& sg = SINGLE ? a.seg0 : seg_s;
   const int C = sg.C, CG = C >> 3, h = sg.h, w = sg.w, TS = sg.ts, HS = TS + 2;
-  const int t = blockIdx.x - sg.tile_begin;
+  const int t = MODE == 2 ? 0 : blockIdx.x - sg.tile_begin;
   const int b = blockIdx.y;                 // grid = (tiles of one image over all segments, batch)
   const int y0 = (t / sg.tiles_x) * TS, x0 = (t % sg.tiles_x) * TS;
   const int CH = C + PAD;                   // halo and operand-tile row pitch (elements)
@@ -237,8 +248,8 @@ __global__ __launch_bounds__(SEP_THREADS_OF(SINGLE), 4) void sep_kernel(SepArgs 
   __syncthreads();
 
   // ---- phase 4: coalesced copy-out ----
-  if (a.dbg_skip & 8) return;
-  if (sg.out_f32) {
+  if (a.dbg_skip & 8) {
+  } else if (sg.out_f32) {
     // head result [B, N_anchors, K]: pixel p owns 9*K consecutive floats; this segment's Nc columns
     float* o = reinterpret_cast<float*>(sg.out) + (int64_t)b * sg.out_bstride + sg.out_off;
     const int npx = rows_valid * cols_valid;
@@ -265,6 +276,10 @@ __global__ __launch_bounds__(SEP_THREADS_OF(SINGLE), 4) void sep_kernel(SepArgs 
       if constexpr (!BF16) *reinterpret_cast<u32x4*>(dst + 4) = *reinterpret_cast<const u32x4*>(src + 16);
     }
   }
+  // chain mode: this node's stores must have landed (and every LDS reader be done) before the next
+  // node of the chain gathers them - same workgroup, same CU, so a barrier after vmcnt(0) suffices
+  if (MODE == 2) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
+  }   // chain loop
 }
 
 void sep_lds_layout(int C, int bf16, int ts, int max_cols_f32, int max_cols_map, SepArgs* a) {
@@ -281,8 +296,9 @@ void sep_lds_layout(int C, int bf16, int ts, int max_cols_f32, int max_cols_map,
 }
 
 int sep_prepare(void) {
-  const void* fns[4] = {reinterpret_cast<const void*>(sep_kernel<true, true>), reinterpret_cast<const void*>(sep_kernel<true, false>),
-                        reinterpret_cast<const void*>(sep_kernel<false, true>), reinterpret_cast<const void*>(sep_kernel<false, false>)};
+  const void* fns[6] = {reinterpret_cast<const void*>(sep_kernel<true, 0>), reinterpret_cast<const void*>(sep_kernel<true, 1>),
+                        reinterpret_cast<const void*>(sep_kernel<true, 2>), reinterpret_cast<const void*>(sep_kernel<false, 0>),
+                        reinterpret_cast<const void*>(sep_kernel<false, 1>), reinterpret_cast<const void*>(sep_kernel<false, 2>)};
   for (const void* f : fns)
     if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024) != hipSuccess) return -1;
   return 0;
@@ -292,12 +308,16 @@ void launch_sep(const SepArgs& a_, hipStream_t s) {
   SepArgs a = a_;
   static const int skip = getenv("HEP_SEP_SKIP") ? atoi(getenv("HEP_SEP_SKIP")) : 0;   // timing experiments only (results are wrong)
   a.dbg_skip = skip;
-  dim3 grid(a.total_tiles, a.B);
+  const int mode = a.chain ? 2 : (a.nseg == 1 ? 0 : 1);
+  dim3 grid(mode == 2 ? 1 : a.total_tiles, a.B);
+  const dim3 block(SEP_THREADS_OF(mode));
   if (a.bf16) {
-    if (a.nseg == 1) hipLaunchKernelGGL((sep_kernel<true, true>), grid, dim3(SEP_THREADS_OF(true)), a.lds_bytes, s, a);
-    else hipLaunchKernelGGL((sep_kernel<true, false>), grid, dim3(SEP_THREADS_OF(false)), a.lds_bytes, s, a);
+    if (mode == 0) hipLaunchKernelGGL((sep_kernel<true, 0>), grid, block, a.lds_bytes, s, a);
+    else if (mode == 1) hipLaunchKernelGGL((sep_kernel<true, 1>), grid, block, a.lds_bytes, s, a);
+    else hipLaunchKernelGGL((sep_kernel<true, 2>), grid, block, a.lds_bytes, s, a);
   } else {
-    if (a.nseg == 1) hipLaunchKernelGGL((sep_kernel<false, true>), grid, dim3(SEP_THREADS_OF(true)), a.lds_bytes, s, a);
-    else hipLaunchKernelGGL((sep_kernel<false, false>), grid, dim3(SEP_THREADS_OF(false)), a.lds_bytes, s, a);
+    if (mode == 0) hipLaunchKernelGGL((sep_kernel<false, 0>), grid, block, a.lds_bytes, s, a);
+    else if (mode == 1) hipLaunchKernelGGL((sep_kernel<false, 1>), grid, block, a.lds_bytes, s, a);
+    else hipLaunchKernelGGL((sep_kernel<false, 2>), grid, block, a.lds_bytes, s, a);
   }
 }
