@@ -52,7 +52,12 @@ void launch_op(const Session& s, const Op& op, int batch, hipStream_t st, const 
     case OP_POOL: { PoolArgs a = op.pool; a.B = batch; launch_pool(a, st); break; }
     case OP_MBF: { MbfArgs a = op.mbf; a.B = batch; launch_mbf(a, st); break; }
     case OP_HEAD: { HeadArgs a = op.head; a.B = batch; launch_head(a, st); break; }
-    case OP_SEP: { SepArgs a = op.sep; a.B = batch; launch_sep(a, st); break; }
+    case OP_SEP: {
+      SepArgs a = op.sep; a.B = batch;
+      if (a.stream) { a.stream_blocks = std::max(1, std::min(a.total_tiles, (256 + batch - 1) / batch)); launch_sep_stream(a, st); }
+      else launch_sep(a, st);
+      break;
+    }
   }
 }
 
@@ -432,7 +437,9 @@ int hep_kernel_symbol(const hep_handle* h, int i, const char** symbol) {
     case OP_POOL: snprintf(tmp, sizeof tmp, "pool_kernel<%s>", t); break;
     case OP_MBF: snprintf(tmp, sizeof tmp, "mbf_kernel<%s, %d, %d>", t, o.mbf.k, o.mbf.s); break;
     case OP_HEAD: snprintf(tmp, sizeof tmp, "head_kernel<%s>", t); break;
-    default: snprintf(tmp, sizeof tmp, "sep_kernel<%s, %d>", t, o.sep.chain ? 2 : (o.sep.nseg == 1 ? 0 : 1)); break;
+    default: if (o.sep.stream) snprintf(tmp, sizeof tmp, "sep_stream_kernel<%s>", t);
+             else snprintf(tmp, sizeof tmp, "sep_kernel<%s, %d>", t, o.sep.chain ? 2 : (o.sep.nseg == 1 ? 0 : 1));
+             break;
   }
   buf = tmp; *symbol = buf.c_str();
   return 0;

@@ -88,6 +88,7 @@ struct SepArgs {
   SepSeg seg0;                               // the only segment of a single-segment launch (kernel argument)
   int nseg; int B; int total_tiles; int bf16; int C;
   int chain;                                 // segments are a dependency chain run by one workgroup per image
+  int stream, stream_blocks;                 // streaming kernel (k_sepstream.hip): workgroups per image, each a run of tiles
   size_t off_atile, off_wdw, off_bias, lds_bytes;   // LDS layout (k_sep.hip: sep_lds_layout)
   int dbg_skip;                              // HEP_SEP_SKIP phase mask (timing experiments only)
 };
@@ -140,6 +141,8 @@ void launch_mbf(const MbfArgs&, hipStream_t);
 size_t mbf_lds_layout(int Cin, int CC, int k, int s, int bf16, int has_expand, MbfArgs* a);
 int mbf_prepare(void);
 void launch_sep(const SepArgs&, hipStream_t);
+void launch_sep_stream(const SepArgs&, hipStream_t);
+int sep_stream_prepare(void);
 void launch_head(const HeadArgs&, hipStream_t);
 void head_lds_layout(int C, int depth, int ts, int bf16, int chunk, HeadArgs* a);
 int head_prepare(void);

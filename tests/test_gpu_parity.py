@@ -194,10 +194,12 @@ def test_module_dropin_and_pipeline(api):
         assert np.array_equal(got.numpy(), want)
 
 
-@pytest.mark.parametrize("env", [{"HEP_MBF": "all"}, {"HEP_MBF": "none"}, {"HEP_HEAD": "fused"}, {"HEP_LANES": "2"}])
+@pytest.mark.parametrize("env", [{"HEP_MBF": "all"}, {"HEP_MBF": "none", "HEP_DWLDS": "0"}, {"HEP_DWLDS": "1", "HEP_MBF": "none"},
+                                 {"HEP_HEAD": "fused"}, {"HEP_LANES": "2"}, {"HEP_CHAIN": "1"}, {"HEP_STREAM": "1"}])
 def test_alternative_plans_keep_parity(api, env, monkeypatch):
     """The planner picks between implementations by measurement (fused MBConv front vs expand+depthwise,
-    fused heads vs per-layer, batch lanes); every alternative must produce the same numbers."""
+    fused heads vs per-layer vs streaming, node chains, LDS depthwise, batch lanes); every alternative must
+    produce the same numbers."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     phi, size, batch = 0, 256, 3
