@@ -44,6 +44,7 @@ SYMBOLS = {
     "hep_kernel_info": (c_int, [_P, c_int, c_int, POINTER(c_char_p), POINTER(c_double), POINTER(c_double)]),
     "hep_kernel_symbol": (c_int, [_P, c_int, POINTER(c_char_p)]),
     "hep_profile": (c_int, [_P, c_int, c_int, POINTER(c_float), _FP]),
+    "hep_profile_concurrent": (c_int, [_P, c_int, c_int, c_int, _FP]),
 }
 
 

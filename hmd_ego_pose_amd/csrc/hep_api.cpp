@@ -5,6 +5,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
 #include <fstream>
 #include <memory>
 
@@ -54,7 +55,8 @@ void launch_op(const Session& s, const Op& op, int batch, hipStream_t st, const 
     case OP_HEAD: { HeadArgs a = op.head; a.B = batch; launch_head(a, st); break; }
     case OP_SEP: {
       SepArgs a = op.sep; a.B = batch;
-      if (a.stream) { a.stream_blocks = std::max(1, std::min(a.total_tiles, (256 + batch - 1) / batch)); launch_sep_stream(a, st); }
+      if (a.direct) launch_tower(a, st);
+      else if (a.stream) { a.stream_blocks = std::max(1, std::min(a.total_tiles, (256 + batch - 1) / batch)); launch_sep_stream(a, st); }
       else launch_sep(a, st);
       break;
     }
@@ -437,7 +439,8 @@ int hep_kernel_symbol(const hep_handle* h, int i, const char** symbol) {
     case OP_POOL: snprintf(tmp, sizeof tmp, "pool_kernel<%s>", t); break;
     case OP_MBF: snprintf(tmp, sizeof tmp, "mbf_kernel<%s, %d, %d>", t, o.mbf.k, o.mbf.s); break;
     case OP_HEAD: snprintf(tmp, sizeof tmp, "head_kernel<%s>", t); break;
-    default: if (o.sep.stream) snprintf(tmp, sizeof tmp, "sep_stream_kernel<%s>", t);
+    default: if (o.sep.direct) snprintf(tmp, sizeof tmp, "tower_kernel<%s, %d, %s>", t, o.sep.C, o.sep.direct == 2 ? "true" : "false");
+             else if (o.sep.stream) snprintf(tmp, sizeof tmp, "sep_stream_kernel<%s>", t);
              else snprintf(tmp, sizeof tmp, "sep_kernel<%s, %d>", t, o.sep.chain ? 2 : (o.sep.nseg == 1 ? 0 : 1));
              break;
   }
@@ -485,6 +488,36 @@ int hep_profile(hep_handle* h, int batch, int iters, float* total_ms_per_iter, f
     for (auto& e : ev) hipEventDestroy(e);
   }
   hipEventDestroy(e0); hipEventDestroy(e1);
+  return 0;
+}
+
+int hep_profile_concurrent(hep_handle* h, int batch, int iters, int nstreams, float* per_kernel_ms) {
+  if (!h || iters < 1 || nstreams < 1 || nstreams > 16 || !per_kernel_ms) return fail(HEP_ERR_INVALID, "bad argument");
+  Session& s = h->s;
+  if (batch < 1 || batch > s.max_batch) return fail(HEP_ERR_UNSUPPORTED, "batch outside 1..max_batch");
+  std::lock_guard<std::mutex> lk(s.mu);
+  HIPRET(hipSetDevice(s.device));
+  const size_t in_floats = (size_t)3 * s.size * s.size;
+  if (!s.d_in) { HIPRET(hipMalloc((void**)&s.d_in, in_floats * s.max_batch * 4)); HIPRET(hipMemset(s.d_in, 0, in_floats * s.max_batch * 4)); }
+  std::string err;
+  const int64_t S = s.size; const int64_t st[4] = {3 * S * S, S * S, S, 1};
+  if (int rc = run_forward(&s, s.d_in, st, batch, s.stream, &err)) return fail(rc, err);
+  HIPRET(hipStreamSynchronize(s.stream));
+  std::vector<hipStream_t> ss(nstreams);
+  for (auto& x : ss) HIPRET(hipStreamCreateWithFlags(&x, hipStreamNonBlocking));
+  const size_t n = s.ops.size();
+  for (size_t k = 0; k < n; k++) {
+    // the same launch repeated on every stream at once (identical inputs, identical outputs): its
+    // time per launch with the chip shared is what the launch costs a pipeline of batches in flight
+    for (int rep = 0; rep < 2; rep++) {
+      auto t0 = std::chrono::steady_clock::now();
+      for (int i = 0; i < (rep ? iters : 2); i++)
+        for (auto& x : ss) launch_op(s, s.lane_ops[0][k], s.lane_count(batch, 0), x, s.d_in, st);
+      for (auto& x : ss) HIPRET(hipStreamSynchronize(x));
+      if (rep) per_kernel_ms[k] = (float)(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / (iters * nstreams));
+    }
+  }
+  for (auto& x : ss) hipStreamDestroy(x);
   return 0;
 }
 

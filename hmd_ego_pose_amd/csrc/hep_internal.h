@@ -89,6 +89,7 @@ struct SepArgs {
   int nseg; int B; int total_tiles; int bf16; int C;
   int chain;                                 // segments are a dependency chain run by one workgroup per image
   int stream, stream_blocks;                 // streaming kernel (k_sepstream.hip): workgroups per image, each a run of tiles
+  int direct;                                // k_tower.hip (wave-per-patch, no LDS staging): 1 = map layer, 2 = headers
   size_t off_atile, off_wdw, off_bias, lds_bytes;   // LDS layout (k_sep.hip: sep_lds_layout)
   int dbg_skip;                              // HEP_SEP_SKIP phase mask (timing experiments only)
 };
@@ -143,6 +144,12 @@ int mbf_prepare(void);
 void launch_sep(const SepArgs&, hipStream_t);
 void launch_sep_stream(const SepArgs&, hipStream_t);
 int sep_stream_prepare(void);
+void launch_tower(const SepArgs&, hipStream_t);
+#define TOWER_BIAS_MAX 384       // bias floats staged per segment: >= 16 * n-tiles of any segment (24 map tiles, 12 per header chunk)
+#define TOWER_HDR_TILES 12       // n-tiles (16 columns) per header segment; wider headers are split into segments
+int tower_prepare(void);         // raises the dynamic-LDS limit of the tower kernels (call once per device)
+int tower_supports(int C);       // BiFPN widths k_tower.hip is instantiated for
+int tower_map_tiles(int C);      // n-tiles (even) of a map layer: its weight rows are permuted, see k_tower.hip
 void launch_head(const HeadArgs&, hipStream_t);
 void head_lds_layout(int C, int depth, int ts, int bf16, int chunk, HeadArgs* a);
 int head_prepare(void);

@@ -427,7 +427,21 @@ struct Planner {
     const int op = new_op(OP_SEP, name);
     int tile_begin = 0, ts_max = 8, cols_f32 = 0, cols_map = 0;
     double bytes = 0, flops = 0, wbytes = 0;
-    const int chunk_cols = SEP_MAX_TILES_N * 16;
+    // head layers (many independent single-source segments, all maps or all head outputs) run on the
+    // wave-per-patch kernel of k_tower.hip; HEP_TOWER=0 keeps them on the tiled kernel of k_sep.hip
+    int direct = 0;
+    {
+      const char* e = getenv("HEP_TOWER");
+      bool simple = specs.size() > 1 && !chain && tower_supports(C) && !(e && atoi(e) == 0);
+      bool maps = true, heads = true;
+      for (const SegSpec& sp : specs) {
+        simple = simple && sp.nsrc == 1 && sp.kind[0] == SRC_SAME && !sp.pre_act && sp.fw[0] == 1.f;
+        maps = maps && sp.out_t >= 0 && sp.N == C; heads = heads && sp.out_t < 0;
+      }
+      if (simple && (maps || heads)) direct = maps ? 1 : 2;
+    }
+    const int chunk_cols = (direct ? TOWER_HDR_TILES : SEP_MAX_TILES_N) * 16;
+    int tiles_n_max = 0;
     for (size_t i = 0; i < specs.size(); i++) {
       const SegSpec& sp = specs[i];
       const int hw = s->levels[sp.level];
@@ -452,11 +466,16 @@ struct Planner {
           sg.kind[j] = sp.kind[j]; sg.fw[j] = sp.fw[j]; sg.sh[j] = t.H; sg.sw[j] = t.W;
           int pb, pa; same_pad(t.H, 3, 2, &pb, &pa); sg.pool_pad[j] = pb;
         }
-        const int tilesN = (Nc + 15) / 16;
+        const int tilesN = direct == 1 ? tower_map_tiles(C) : (Nc + 15) / 16;
+        tiles_n_max = std::max(tiles_n_max, tilesN);
         std::vector<float> wf((size_t)tilesN * 16 * C, 0.f), bf((size_t)tilesN * 16, 0.f);
         for (int n = 0; n < Nc; n++) {
           const float sc = sp.bn.empty() ? 1.f : bn.scale[n0 + n], sh = sp.bn.empty() ? 0.f : bn.shift[n0 + n];
-          for (int k = 0; k < C; k++) wf[(size_t)n * C + k] = wp->data[(size_t)(n0 + n) * C + k] * sc;
+          // k_tower.hip map layers: MFMA row (nt, i) holds channel (i/4)*RUN + 4*nt + i%4 (RUN = 4*tilesN),
+          // so that a lane's results over the n-tiles are consecutive channels
+          int row = n;
+          if (direct == 1) { const int run = 4 * tilesN, gq = n / run, rem = n % run; row = (rem / 4) * 16 + gq * 4 + rem % 4; }
+          for (int k = 0; k < C; k++) wf[(size_t)row * C + k] = wp->data[(size_t)(n0 + n) * C + k] * sc;
           bf[n] = bp->data[n0 + n] * sc + sh;
         }
         sg.N = Nc; sg.tilesN = tilesN; sg.act = sp.act; sg.n_base = n0;
@@ -491,7 +510,9 @@ struct Planner {
       const char* e = getenv("HEP_STREAM");
       o.sep.stream = simple && e && atoi(e) != 0;
     }
+    o.sep.direct = direct;
     sep_lds_layout(C, s->dtype, ts_max, cols_f32, cols_map, &o.sep);
+    if (direct) { o.sep.stream = 0; o.sep.off_wdw = 0; o.sep.off_bias = (size_t)9 * C * 4; o.sep.lds_bytes = o.sep.off_bias + (size_t)tiles_n_max * 16 * 4; }
     if (o.sep.lds_bytes > 160 * 1024) { *err = "BiFPN width too large for the fused separable-conv tile"; ok = false; return; }
     o.act_bytes_per_image = bytes; o.flops_per_image = flops; o.weight_bytes = wbytes;
   }
@@ -788,6 +809,7 @@ int build_session(Session* s, const Pack& pack, std::string* err) {
   if (mbf_prepare() != 0) { *err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for mbf_kernel"; return HEP_ERR_DEVICE; }
   if (head_prepare() != 0) { *err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for head_kernel"; return HEP_ERR_DEVICE; }
   if (sep_stream_prepare() != 0) { *err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for sep_stream_kernel"; return HEP_ERR_DEVICE; }
+  if (tower_prepare() != 0) { *err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for tower_kernel"; return HEP_ERR_DEVICE; }
   if (sep_prepare() != 0) { *err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"; return HEP_ERR_DEVICE; }
   HIPCHK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
   s->weights_bytes = P.wb.host.size();

@@ -1,0 +1,388 @@
+// k_tower.hip - the head layers (tower SeparableConvBlocks and the header convs of all five heads)
+// as barrier-free, wave-independent work on gfx950:
+//
+//   depthwise 3x3 SAME (no bias) -> pointwise 1x1 (+bias, per-level BN folded) -> swish | sigmoid | none
+//
+// reference: efficientdet/model.py:361-417 (Regressor / Classifier), hmdegopose/model.py:55-90,
+// 127-156, 191-228 (rotation / translation / hand nets): `conv(feat); bn(feat); swish(feat)` per
+// tower layer, then the header conv + permute/view/cat into [B, N_anchors, K].
+//
+// k_sep.hip runs the same math one 8x8 tile per workgroup through five LDS phases; with ~1800 tiny
+// workgroups per layer its time is the per-workgroup latency chain, not bandwidth.  Here every WAVE
+// owns one 16-pixel MFMA m-tile (a 4x4 patch; 4 waves = one 8x8 tile so neighbours share L1 lines):
+//   1. each lane loads the 9 taps of ITS pixel x 8 (bf16) / 4 (fp32) channels straight from global
+//      memory - exactly the channels it holds in the MFMA operand - and accumulates the depthwise
+//      conv in registers; the operand never exists in memory or LDS,
+//   2. maps:    D[n, pixel] = W . X^T  (weights as A operand): a lane ends with 4 consecutive
+//               channels of one pixel; the planner permutes the weight rows so that two n-tiles give
+//               8 consecutive channels -> one 16-byte store straight to the NHWC map,
+//      headers: D[pixel, n] = X . W^T  (pixels as A operand): 16 consecutive lanes hold 16
+//               consecutive columns of a pixel -> 64-byte runs of the [B, N_anchors, K] result.
+// LDS holds the depthwise weights + bias (one barrier) and a wave-private slot for the finished
+// operand fragments.
+#include <stdlib.h>
+
+#include <algorithm>
+#include <type_traits>
+
+#include "hep_dev.h"
+#include "hep_internal.h"
+
+// Optional per-wave timeline (make EXTRA=-DHEP_TOWER_TRACE): every wave stamps s_memrealtime (100 MHz)
+// at its phase boundaries into a device buffer read back with hep_dbg_tower_trace() - a profiling build
+// only, the stamps are compiled out of the product library.
+#ifdef HEP_TOWER_TRACE
+__device__ unsigned long long* g_tower_trace = nullptr;
+#define TSTAMP(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define TSTAMP_NOWAIT(i) do { stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define TSTAMP(i)
+#define TSTAMP_NOWAIT(i)
+#endif
+
+#define GLOBAL __attribute__((address_space(1)))   // pointers read from the descriptor are global, not flat
+
+namespace {
+
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+// One MFMA operand fragment (8 bf16 / 4 fp32 channels of one pixel) and the depthwise accumulation over
+// it.  bf16: the even channels of two packed words are unpacked with one shift each, the odd ones with
+// one mask each, and every pair feeds one v_pk_fma_f32 - so the accumulators (and the depthwise
+// weights in LDS, see `swz`) are kept in the order 0,2,1,3 | 4,6,5,7.
+template <bool BF16> struct Frag;
+template <> struct Frag<true> {
+  typedef u32x4 raw;
+  struct Acc { f32x2 a[4]; };      // channels (0,2) (1,3) (4,6) (5,7)
+  static __device__ __forceinline__ f32x4 swz(f32x4 w) { return (f32x4){w[0], w[2], w[1], w[3]}; }
+  static __device__ __forceinline__ void zero(Acc& c) { for (int i = 0; i < 4; i++) c.a[i] = (f32x2){0.f, 0.f}; }
+  static __device__ __forceinline__ void fma_tap(Acc& c, const raw& x, const float* w /* 8 swizzled weights in LDS */) {
+    const f32x4 wa = reinterpret_cast<const f32x4*>(w)[0], wb = reinterpret_cast<const f32x4*>(w)[1];
+    const f32x2 e0 = {__uint_as_float(x[0] << 16), __uint_as_float(x[1] << 16)}, o0 = {__uint_as_float(x[0] & 0xffff0000u), __uint_as_float(x[1] & 0xffff0000u)};
+    const f32x2 e1 = {__uint_as_float(x[2] << 16), __uint_as_float(x[3] << 16)}, o1 = {__uint_as_float(x[2] & 0xffff0000u), __uint_as_float(x[3] & 0xffff0000u)};
+    c.a[0] = __builtin_elementwise_fma(e0, (f32x2){wa[0], wa[1]}, c.a[0]);
+    c.a[1] = __builtin_elementwise_fma(o0, (f32x2){wa[2], wa[3]}, c.a[1]);
+    c.a[2] = __builtin_elementwise_fma(e1, (f32x2){wb[0], wb[1]}, c.a[2]);
+    c.a[3] = __builtin_elementwise_fma(o1, (f32x2){wb[2], wb[3]}, c.a[3]);
+  }
+  static __device__ __forceinline__ raw pack(const Acc& c) {
+    return (raw){pack_bf16x2(c.a[0][0], c.a[1][0]), pack_bf16x2(c.a[0][1], c.a[1][1]), pack_bf16x2(c.a[2][0], c.a[3][0]), pack_bf16x2(c.a[2][1], c.a[3][1])};
+  }
+  static __device__ __forceinline__ f32x4 mma(const raw& a, const raw& b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+};
+template <> struct Frag<false> {
+  typedef f32x4 raw;
+  struct Acc { f32x4 a; };
+  static __device__ __forceinline__ f32x4 swz(f32x4 w) { return w; }
+  static __device__ __forceinline__ void zero(Acc& c) { c.a = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  static __device__ __forceinline__ void fma_tap(Acc& c, const raw& x, const float* w) {
+    c.a = __builtin_elementwise_fma(x, *reinterpret_cast<const f32x4*>(w), c.a);
+  }
+  static __device__ __forceinline__ raw pack(const Acc& c) { return c.a; }
+  static __device__ __forceinline__ f32x4 mma(const raw& a, const raw& b, f32x4 c) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], b[q], c, 0, 0, 0);
+    return c;
+  }
+};
+
+}  // namespace
+
+// LDS layout of one workgroup (4 waves), shared with tower_lds_bytes():
+//   [9*CW] f32 depthwise weights | [TOWER_BIAS_MAX] f32 bias | 4 waves x KS x 64 lanes operand fragments
+//   | (when it fits in 48 KB) the segment's pointwise weights, rows padded against bank conflicts
+template <bool BF16, int CW, bool HDR> struct TowerCfg {
+  static constexpr int ES = BF16 ? 2 : 4;
+  static constexpr int KL = BF16 ? 8 : 4, KSTEP = 4 * KL, KS = (CW + KSTEP - 1) / KSTEP;
+  static constexpr int NTMAP = (((CW + 15) / 16) + 1) & ~1;           // n-tiles of a map layer (even)
+  static constexpr int WROWS = (HDR ? TOWER_HDR_TILES : NTMAP) * 16;  // most weight rows a segment has
+  static constexpr int WP = CW + (BF16 ? 8 : 4);                      // LDS row pitch (elements)
+  static constexpr bool WLDS = (size_t)WROWS * WP * ES <= 48 * 1024;
+  static constexpr size_t OFF_XA = ((size_t)9 * CW + TOWER_BIAS_MAX) * 4;
+  static constexpr size_t OFF_W = OFF_XA + (size_t)4 * KS * 64 * 16;
+  static constexpr size_t LDS = OFF_W + (WLDS ? (size_t)WROWS * WP * ES : 0);
+};
+
+template <bool BF16, int CW, bool HDR>
+__global__ __launch_bounds__(256, BF16 ? 4 : 2) void tower_kernel(const SepSeg* __restrict__ segs, const int* __restrict__ tile_seg, int B, int ipb, int dbg) {
+  typedef Frag<BF16> F;
+  typedef typename F::raw raw_t;
+  typedef typename Vec8<BF16>::elem T;
+  typedef TowerCfg<BF16, CW, HDR> Cfg;
+  constexpr int KL = Cfg::KL, KSTEP = Cfg::KSTEP, KS = Cfg::KS, ES = Cfg::ES, WP = Cfg::WP;
+  constexpr bool KFULL = CW % KSTEP == 0, WLDS = Cfg::WLDS;
+  constexpr int G = KS <= 2 ? KS : (BF16 ? 1 : 2), NG = (KS + G - 1) / G;   // k-steps whose 9 tap loads are in flight together
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#ifdef HEP_TOWER_TRACE
+  unsigned long long stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  TSTAMP_NOWAIT(0);
+#endif
+  float* wdw_s = reinterpret_cast<float*>(smem);
+  float* bias_s = wdw_s + 9 * CW;
+  T* w_s = reinterpret_cast<T*>(smem + Cfg::OFF_W);
+
+  const int si = __builtin_amdgcn_readfirstlane(tile_seg[blockIdx.x]);
+  const SepSeg* __restrict__ sg = segs + si;           // uniform + read-only: descriptor fields arrive as scalar loads
+  const int h = sg->h, w = sg->w, tiles_x = sg->tiles_x, tilesN = sg->tilesN;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
+  const GLOBAL T* W = (const GLOBAL T*)sg->wpw;
+  TSTAMP(1);                           // descriptor arrived
+  // ---- stage the layer's weights (overlaps with the tap loads issued below) ----
+  // (every load of the staging is issued before the first LDS store: one memory round trip, not one per
+  //  loop iteration)
+  {
+    constexpr int NDW = (9 * CW / 4 + 255) / 256, NB = (TOWER_BIAS_MAX / 4 + 255) / 256;
+    constexpr int VPR = CW / KL, NW = WLDS ? (Cfg::WROWS * VPR + 255) / 256 : 0;
+    const GLOBAL f32x4* gdw = (const GLOBAL f32x4*)sg->wdw;
+    const GLOBAL f32x4* gb = (const GLOBAL f32x4*)sg->bias;
+    f32x4 vdw[NDW], vb[NB];
+    raw_t vw[NW > 0 ? NW : 1];
+#pragma unroll
+    for (int j = 0; j < NDW; j++) { const int i = threadIdx.x + j * 256; if (i < 9 * CW / 4) vdw[j] = gdw[i]; }
+#pragma unroll
+    for (int j = 0; j < NB; j++) { const int i = threadIdx.x + j * 256; if (i < tilesN * 4) vb[j] = gb[i]; }
+#pragma unroll
+    for (int j = 0; j < NW; j++) {
+      const int i = threadIdx.x + j * 256, row = i / VPR, v = i - row * VPR;
+      if (i < tilesN * 16 * VPR) vw[j] = *(const GLOBAL raw_t*)(W + row * CW + v * KL);
+    }
+#pragma unroll
+    for (int j = 0; j < NDW; j++) { const int i = threadIdx.x + j * 256; if (i < 9 * CW / 4) reinterpret_cast<f32x4*>(wdw_s)[i] = F::swz(vdw[j]); }
+#pragma unroll
+    for (int j = 0; j < NB; j++) { const int i = threadIdx.x + j * 256; if (i < tilesN * 4) reinterpret_cast<f32x4*>(bias_s)[i] = vb[j]; }
+#pragma unroll
+    for (int j = 0; j < NW; j++) {
+      const int i = threadIdx.x + j * 256, row = i / VPR, v = i - row * VPR;
+      if (i < tilesN * 16 * VPR) *reinterpret_cast<raw_t*>(w_s + row * WP + v * KL) = vw[j];
+    }
+  }
+
+  // one workgroup = one 8x8 tile position of `ipb` consecutive images: the staged weights are shared
+  // and the taps of image i+1 are in flight while image i goes through the MFMAs
+  const int t = blockIdx.x - sg->tile_begin;
+  const int b0 = blockIdx.y * ipb, nimg = min(ipb, B - b0);
+  const int ty = t / tiles_x, tx = t - ty * tiles_x;
+  const int y0 = ty * 8 + (wave >> 1) * 4, x0 = tx * 8 + (wave & 1) * 4;   // this wave's 4x4 patch
+  const int y = y0 + (r >> 2), x = x0 + (r & 3);                            // this lane's pixel (MFMA row/col r)
+  const bool pix_ok = y < h && x < w;
+
+  // ---- depthwise 3x3 in registers: lane = (pixel r, channels ks*KSTEP + KL*g ..) ----
+  // taps are raw buffer loads of one image: a tap in the SAME padding (or of a lane without a pixel)
+  // gets an out-of-range offset and the hardware returns zeros - no branches, no masking
+  const int img_elems = h * w * CW;
+  const GLOBAL T* X0 = (const GLOBAL T*)sg->src[0] + (int64_t)b0 * img_elems;
+  constexpr uint32_t OOB = 0x80000000u;
+  uint32_t toff[9];
+#pragma unroll
+  for (int q = 0; q < 9; q++) {
+    const int iy = y + q / 3 - 1, ix = x + q % 3 - 1;
+    const bool ok = pix_ok && iy >= 0 && iy < h && ix >= 0 && ix < w;
+    toff[q] = ok ? (uint32_t)((iy * w + ix) * CW + KL * g) * ES : OOB;
+  }
+  raw_t tp[G][9];
+  auto load_group = [&](int bi, int gi) {
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)(X0 + (int64_t)bi * img_elems), 0, img_elems * ES, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < G; j++) {
+      const int ks = gi * G + j;
+      if (ks < KS) {
+        const bool kok = KFULL || ks * KSTEP + KL * g < CW;
+#pragma unroll
+        for (int q = 0; q < 9; q++)
+          tp[j][q] = __builtin_bit_cast(raw_t, __builtin_amdgcn_raw_buffer_load_b128(xrs, kok ? toff[q] : OOB, ks * KSTEP * ES, 0));
+      }
+    }
+  };
+  raw_t* xa_s = reinterpret_cast<raw_t*>(smem + Cfg::OFF_XA) + wave * KS * 64 + lane;
+  if (!(dbg & 2)) load_group(0, 0);
+  TSTAMP_NOWAIT(2);                    // staging + first taps issued
+  __syncthreads();                     // weights are in LDS; the first taps are in flight
+  TSTAMP_NOWAIT(3);                    // barrier passed
+  if (y0 >= h || x0 >= w || (dbg & 1)) return;      // patch entirely outside the map
+
+  // pointwise weight fragment of MFMA row `row`, k-step ks (zero where k >= CW)
+  auto wfrag = [&](int row, int ks) -> raw_t {
+    const bool kok = KFULL || ks * KSTEP + KL * g < CW;
+    const int k = kok ? ks * KSTEP + KL * g : 0;
+    raw_t v;
+    if constexpr (WLDS) v = *reinterpret_cast<const raw_t*>(w_s + row * WP + k);
+    else v = *(const GLOBAL raw_t*)(W + row * CW + k);
+    if (!KFULL && !kok) v = raw_t{};
+    return v;
+  };
+  const int N = sg->N, act = sg->act;
+  constexpr int KU = KS < 4 ? KS : 4;   // k-steps of weight fragments in flight
+
+#pragma unroll 1
+  for (int bi = 0; bi < nimg; bi++) {
+  const int b = b0 + bi;
+#pragma unroll 1
+  for (int gi = 0; gi < ((dbg & 2) ? 0 : NG); gi++) {
+#pragma unroll
+    for (int j = 0; j < G; j++) {
+      const int ks = gi * G + j;
+      if (ks < KS) {
+        const int k = ks * KSTEP + KL * g;
+        const float* wl = wdw_s + ((KFULL || k < CW) ? k : 0);
+        typename F::Acc acc;
+        F::zero(acc);
+#pragma unroll
+        for (int q = 0; q < 9; q++) F::fma_tap(acc, tp[j][q], wl + q * CW);
+        xa_s[ks * 64] = F::pack(acc);
+      }
+    }
+    if (gi + 1 < NG) load_group(bi, gi + 1);
+  }
+  if (bi + 1 < nimg && !(dbg & 2)) load_group(bi + 1, 0);     // next image's taps fly during the MFMA phase
+  TSTAMP_NOWAIT(4);                    // depthwise done (fragments in LDS)
+  if (dbg & 4) continue;
+  if constexpr (!HDR) {
+    // ---- maps: lane (r, g) owns channels g*RUN + 4*nt .. +3 of pixel r for every n-tile nt ----
+    constexpr int NT = Cfg::NTMAP, RUN = 4 * NT;
+    GLOBAL T* O = (GLOBAL T*)sg->out + (int64_t)b * sg->out_bstride + sg->out_off + ((int64_t)y * w + x) * sg->out_rowstride;
+#pragma unroll(NT <= 4 ? 2 : 1)
+    for (int nt = 0; nt < NT; nt += 2) {
+      const int ch = g * RUN + nt * 4;
+      f32x4 acc0 = *reinterpret_cast<const f32x4*>(bias_s + ch), acc1 = *reinterpret_cast<const f32x4*>(bias_s + ch + 4);
+#pragma unroll(KU)
+      for (int ks = 0; ks < KS; ks++) {
+        const raw_t w0 = wfrag(nt * 16 + r, ks), w1 = wfrag(nt * 16 + 16 + r, ks);
+        const raw_t xv = xa_s[ks * 64];
+        acc0 = F::mma(w0, xv, acc0);
+        acc1 = F::mma(w1, xv, acc1);
+      }
+      if (pix_ok && ch < N) {
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 4; q++) { v[q] = acc0[q]; v[4 + q] = acc1[q]; }
+        if (act == ACT_SWISH) {           // uniform: one branch per n-tile pair, not one per element
+#pragma unroll
+          for (int q = 0; q < 8; q++) v[q] = swish_t<BF16>(v[q]);
+        } else if (act == ACT_SIGMOID) {
+#pragma unroll
+          for (int q = 0; q < 8; q++) v[q] = sigmoid_t<BF16>(v[q]);
+        }
+        if constexpr (BF16) {
+          u32x4 pk;
+#pragma unroll
+          for (int e = 0; e < 4; e++) pk[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
+          if (ch + 8 <= N) *(GLOBAL u32x4*)(O + ch) = pk;
+          else *(GLOBAL u32x2*)(O + ch) = (u32x2){pk[0], pk[1]};
+        } else {
+          *(GLOBAL f32x4*)(O + ch) = (f32x4){v[0], v[1], v[2], v[3]};
+          if (ch + 8 <= N) *(GLOBAL f32x4*)(O + ch + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+        }
+      }
+    }
+  } else {
+    // ---- headers: lane (r, g) owns column nt*16 + r of pixels (y0 + g, x0 + q), q = 0..3 ----
+    GLOBAL float* O = (GLOBAL float*)sg->out + (int64_t)b * sg->out_bstride + sg->out_off;
+    const int kin = sg->col_kin, kout = sg->col_kout, coff = sg->col_off, nbase = sg->n_base;
+    const int64_t rs = sg->out_rowstride;
+    const int ym = y0 + g;
+    const int64_t prow = ((int64_t)ym * w + x0) * rs;
+#pragma unroll 2
+    for (int nt = 0; nt < tilesN; nt++) {
+      const int n = nt * 16 + r;
+      const float bias = bias_s[n];
+      f32x4 acc = (f32x4){bias, bias, bias, bias};
+#pragma unroll(KU)
+      for (int ks = 0; ks < KS; ks++) acc = F::mma(xa_s[ks * 64], wfrag(n, ks), acc);
+      if (n < N && ym < h) {
+        const int nn = nbase + n;
+        const int col = (nn / kin) * kout + nn % kin + coff;
+        if (act == ACT_SIGMOID) {
+#pragma unroll
+          for (int q = 0; q < 4; q++) acc[q] = sigmoid_t<BF16>(acc[q]);
+        } else if (act == ACT_SWISH) {
+#pragma unroll
+          for (int q = 0; q < 4; q++) acc[q] = swish_t<BF16>(acc[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+          if (x0 + q < w) O[prow + q * rs + col] = acc[q];
+      }
+    }
+  }
+  }   // image loop
+#ifdef HEP_TOWER_TRACE
+  TSTAMP_NOWAIT(5);                    // MFMA + stores issued
+  TSTAMP(6);                           // stores acknowledged
+  if (g_tower_trace && lane == 0) {
+    unsigned long long* o = g_tower_trace + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 8;
+    for (int i = 0; i < 7; i++) o[i] = stamps[i];
+    o[7] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
+  }
+#endif
+}
+
+static const int kTowerWidths[] = {64, 88, 112, 160, 224, 288, 384};   // BiFPN widths of phi 0..6 (arch.py)
+
+int tower_supports(int C) {
+  for (int cw : kTowerWidths) if (cw == C) return 1;
+  return 0;
+}
+
+int tower_map_tiles(int C) { return (((C + 15) / 16) + 1) & ~1; }      // n-tiles of a map layer (even)
+
+template <bool BF16, int CW, bool HDR>
+static void launch_one(const SepArgs& a, dim3 grid, hipStream_t s, int ipb, int dbg) {
+  typedef TowerCfg<BF16, CW, HDR> Cfg;
+  hipLaunchKernelGGL((tower_kernel<BF16, CW, HDR>), grid, dim3(256), Cfg::LDS, s, a.segs, a.tile_seg, a.B, ipb, dbg);
+}
+
+template <int CW>
+static void launch_w(const SepArgs& a, dim3 grid, hipStream_t s, int ipb) {
+  const bool hdr = a.direct == 2;
+  static const int dbg = getenv("HEP_TOWER_SKIP") ? atoi(getenv("HEP_TOWER_SKIP")) : 0;   // timing experiments only (results are wrong)
+  if (a.bf16) { if (hdr) launch_one<true, CW, true>(a, grid, s, ipb, dbg); else launch_one<true, CW, false>(a, grid, s, ipb, dbg); }
+  else { if (hdr) launch_one<false, CW, true>(a, grid, s, ipb, dbg); else launch_one<false, CW, false>(a, grid, s, ipb, dbg); }
+}
+
+template <int CW>
+static int prepare_w() {
+  const void* fns[4] = {reinterpret_cast<const void*>(tower_kernel<true, CW, true>), reinterpret_cast<const void*>(tower_kernel<true, CW, false>),
+                        reinterpret_cast<const void*>(tower_kernel<false, CW, true>), reinterpret_cast<const void*>(tower_kernel<false, CW, false>)};
+  for (const void* f : fns)
+    if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024) != hipSuccess) return -1;
+  return 0;
+}
+
+// raises the dynamic-LDS limit of every instantiation (call once per device)
+int tower_prepare(void) {
+  return prepare_w<64>() | prepare_w<88>() | prepare_w<112>() | prepare_w<160>() | prepare_w<224>() | prepare_w<288>() | prepare_w<384>();
+}
+
+#ifdef HEP_TOWER_TRACE
+// profiling build: stamps of the LAST tower launch, [blocks*4 waves][8]; returns the number of waves
+extern "C" int hep_dbg_tower_trace(unsigned long long* host, int max_waves, int enable) {
+  static unsigned long long* buf = nullptr;
+  const size_t cap = (size_t)1 << 20;
+  if (!buf) { if (hipMalloc((void**)&buf, cap * 8) != hipSuccess) return -1; hipMemset(buf, 0, cap * 8); }
+  unsigned long long* p = enable ? buf : nullptr;
+  hipMemcpyToSymbol(HIP_SYMBOL(g_tower_trace), &p, sizeof p);
+  if (host) { hipDeviceSynchronize(); hipMemcpy(host, buf, (size_t)max_waves * 64, hipMemcpyDeviceToHost); }
+  return (int)(cap / 8);
+}
+#endif
+
+void launch_tower(const SepArgs& a, hipStream_t s) {
+  // images per workgroup: amortises the weight staging; keep >= ~1000 workgroups in the launch
+  static const int ipb_env = getenv("HEP_TOWER_IPB") ? atoi(getenv("HEP_TOWER_IPB")) : 0;
+  int ipb = ipb_env > 0 ? ipb_env : 1;
+  if (ipb_env <= 0) while (ipb < 4 && (int64_t)a.total_tiles * ((a.B + 2 * ipb - 1) / (2 * ipb)) >= 900) ipb *= 2;
+  ipb = std::min(ipb, a.B);
+  const dim3 grid(a.total_tiles, (a.B + ipb - 1) / ipb);
+  switch (a.C) {
+    case 64: launch_w<64>(a, grid, s, ipb); break;
+    case 88: launch_w<88>(a, grid, s, ipb); break;
+    case 112: launch_w<112>(a, grid, s, ipb); break;
+    case 160: launch_w<160>(a, grid, s, ipb); break;
+    case 224: launch_w<224>(a, grid, s, ipb); break;
+    case 288: launch_w<288>(a, grid, s, ipb); break;
+    case 384: launch_w<384>(a, grid, s, ipb); break;
+    default: break;   // the planner only selects this kernel for tower_supports(C)
+  }
+}

@@ -42,7 +42,7 @@ def init(backend: Optional[str] = None) -> Tuple[int, int, int]:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         be = backend or ("nccl" if torch.cuda.is_available() else "gloo")
-        if be == "nccl":
+        if torch.cuda.is_available():
             torch.cuda.set_device(local_rank)
         dist.init_process_group(be, rank=rank, world_size=world)
     return rank, local_rank, world

@@ -147,6 +147,13 @@ class Session:
         _capi.check(l.hep_profile(self.handle, batch, iters, ctypes.byref(total), per))
         return total.value, (list(per) if per_kernel else None)
 
+    def profile_concurrent(self, batch: int, iters: int = 20, nstreams: int = 4):
+        """ms per launch of every launch of the plan when it is issued on ``nstreams`` streams at once."""
+        l = _capi.lib()
+        per = (ctypes.c_float * l.hep_kernel_count(self.handle, batch))()
+        _capi.check(l.hep_profile_concurrent(self.handle, batch, iters, nstreams, per))
+        return list(per)
+
 
 # --------------------------------------------------------------------------------------
 # torch custom ops (the "PyTorch-ROCm custom op" face of the C ABI)

@@ -142,6 +142,11 @@ int hep_kernel_symbol(const hep_handle* h, int i, const char** symbol);
  * per_kernel_ms is non-NULL (length hep_kernel_count) also run the forward eagerly with a HIP event
  * in front of every launch and return each launch's average in-sequence duration. */
 int hep_profile(hep_handle* h, int batch, int iters, float* total_ms_per_iter, float* per_kernel_ms);
+/* Throughput cost of every launch: launch i is issued `iters` times on each of `nstreams` HIP streams
+ * at once and per_kernel_ms[i] = wall time / (iters * nstreams).  A launch that fills the chip costs
+ * its full duration, one that leaves CUs idle costs less than it takes alone (bench.py keeps several
+ * batches in flight, so this - not the stand-alone duration - is what a launch costs the pipeline). */
+int hep_profile_concurrent(hep_handle* h, int batch, int iters, int nstreams, float* per_kernel_ms);
 
 #ifdef __cplusplus
 }
