@@ -346,7 +346,9 @@ struct Planner {
       // LDS (the fused kernel without its expand stage) on the 8x8 maps, where the global-memory
       // version is a chain of k*k dependent load latencies.  HEP_DWLDS=0|1 overrides.
       const char* dl = getenv("HEP_DWLDS");
-      const bool lds_dw = dl ? atoi(dl) != 0 : (Hin <= 8);
+      // (measured at bs16: the 5x5 stride-2 layer on the 64x64 map takes 20.6 us through LDS against
+      //  27.2 us from global memory - 25 taps per output re-read too much through L1)
+      const bool lds_dw = dl ? atoi(dl) != 0 : (Hin <= 8 || (b.k == 5 && Hin <= 64));
       const int ccl = std::min(64, b.cexp);
       if (lds_dw && mbf_lds_layout(b.cexp, ccl, b.k, b.stride, s->dtype, 0, nullptr) <= 159 * 1024) {
         nblk = ((Ho + 7) / 8) * ((Wo + 7) / 8);

@@ -11,45 +11,57 @@
 // fp32 tensor is read through its own strides, so the NHWC-memory view that
 // eval/common.py:397 produces needs no copy.
 // ------------------------------------------------------------------------------------------------
+// One lane = one output pixel: its 27 inputs are loaded once (zero outside the image, branch-free)
+// and reused for every group of 8 output channels; the weights of a group are the same for the whole
+// wave, so they arrive through the scalar cache and feed the FMAs as scalar operands.
 template <bool BF16>
 __global__ __launch_bounds__(256) void stem_kernel(StemArgs a) {
-  const int CG = a.Cout >> 3;
-  const int64_t total = (int64_t)a.B * a.Ho * a.Wo * CG;
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= total) return;
-  const int cg = (int)(idx % CG);
-  int64_t p = idx / CG;
-  const int ox = (int)(p % a.Wo); p /= a.Wo;
-  const int oy = (int)(p % a.Ho);
-  const int b = (int)(p / a.Ho);
-  float acc[8];
-#pragma unroll
-  for (int c = 0; c < 8; c++) acc[c] = a.bias[cg * 8 + c];
+  const int ox = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int oy = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int b = blockIdx.z;
+  if (ox >= a.Wo || oy >= a.Ho) return;
+  float x[27];
+  const float* img = a.in + (int64_t)b * a.sn;
 #pragma unroll
   for (int ky = 0; ky < 3; ky++) {
     const int iy = oy * 2 - a.pad_t + ky;
-    if (iy < 0 || iy >= a.H) continue;
+    const int cy = min(max(iy, 0), a.H - 1);
 #pragma unroll
     for (int kx = 0; kx < 3; kx++) {
       const int ix = ox * 2 - a.pad_l + kx;
-      if (ix < 0 || ix >= a.W) continue;
+      const int cx = min(max(ix, 0), a.W - 1);
+      const bool ok = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
 #pragma unroll
       for (int ci = 0; ci < 3; ci++) {
-        const float x = a.in[b * a.sn + ci * a.sc + iy * a.sh + ix * a.sw];
-        const float* w = a.w + ((ky * 3 + kx) * 3 + ci) * a.Cout + cg * 8;
-#pragma unroll
-        for (int c = 0; c < 8; c++) acc[c] = fmaf(x, w[c], acc[c]);
+        const float v = img[ci * a.sc + cy * a.sh + cx * a.sw];
+        x[(ky * 3 + kx) * 3 + ci] = ok ? v : 0.f;
       }
     }
   }
+  const int64_t pix = ((int64_t)b * a.Ho + oy) * a.Wo + ox;
+#pragma unroll 1
+  for (int cg = 0; cg < (a.Cout >> 3); cg++) {
+    // uniform addresses in read-only memory: the constant address space makes them scalar loads
+    // (the compiler cannot prove that the stores below do not alias them)
+    typedef const __attribute__((address_space(4))) float* cptr;
+    cptr w = (cptr)a.w + cg * 8;
+    cptr bias = (cptr)a.bias + cg * 8;
+    float acc[8];
 #pragma unroll
-  for (int c = 0; c < 8; c++) acc[c] = swish_t<BF16>(acc[c]);
-  Vec8<BF16>::store(a.out, idx * 8, acc);
+    for (int c = 0; c < 8; c++) acc[c] = bias[c];
+#pragma unroll
+    for (int t = 0; t < 27; t++) {
+#pragma unroll
+      for (int c = 0; c < 8; c++) acc[c] = fmaf(x[t], w[t * a.Cout + c], acc[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < 8; c++) acc[c] = swish_t<BF16>(acc[c]);
+    Vec8<BF16>::store(a.out, pix * a.Cout + cg * 8, acc);
+  }
 }
 
 void launch_stem(const StemArgs& a, hipStream_t s) {
-  const int64_t total = (int64_t)a.B * a.Ho * a.Wo * (a.Cout >> 3);
-  dim3 grid((unsigned)((total + 255) / 256));
+  dim3 grid((unsigned)((a.Wo + 63) / 64), (unsigned)((a.Ho + 3) / 4), (unsigned)a.B);
   if (a.bf16) hipLaunchKernelGGL(stem_kernel<true>, grid, dim3(256), 0, s, a);
   else hipLaunchKernelGGL(stem_kernel<false>, grid, dim3(256), 0, s, a);
 }

@@ -62,12 +62,17 @@ __global__ __launch_bounds__(MBF_THREADS) void mbf_kernel(MbfArgs a) {
   // ---- phase A: everything this workgroup needs, global -> LDS, all loads issued in batches of 8
   //      before the first LDS store (one memory round trip per batch): depthwise weights + biases,
   //      the expand-weight chunk [cc][K], and the input tile (zero outside the image) ----
-  const int mtiles = (PIN + 15) / 16, ntiles = (cc + 15) / 16;
+  constexpr int mtiles = (PIN + 15) / 16;
+  const int ntiles = (cc + 15) / 16;
   const int ksteps = (K + KSTEP - 1) / KSTEP;
   const int npairs = a.has_expand ? mtiles * ntiles : 0;           // pair = nt * mtiles + mt
-  for (int i = threadIdx.x; i < KS * KS * cc; i += MBF_THREADS) {
-    const int tap = i / cc, c = i % cc;
-    wdw_s[tap * a.CC + c] = a.wdw[(int64_t)tap * a.Cexp + c0 + c];
+  // (index arithmetic: every divisor below is a compile-time constant or a power of two - a run-time
+  //  integer division costs ~30 VALU instructions and this kernel used to spend most of its issue
+  //  slots on them)
+  int ccsh = 3; while ((1 << ccsh) < cc) ccsh++;
+  for (int i = threadIdx.x; i < (KS * KS) << ccsh; i += MBF_THREADS) {
+    const int tap = i >> ccsh, c = i & ((1 << ccsh) - 1);
+    if (c < cc) wdw_s[tap * a.CC + c] = a.wdw[(int64_t)tap * a.Cexp + c0 + c];
   }
   for (int c = threadIdx.x; c < cc; c += MBF_THREADS) { be_s[c] = a.has_expand ? a.be[c0 + c] : 0.f; bdw_s[c] = a.bdw[c0 + c]; }
   {
@@ -78,35 +83,37 @@ __global__ __launch_bounds__(MBF_THREADS) void mbf_kernel(MbfArgs a) {
     T* dst = a.has_expand ? a_s : e_s;
     const int pitch = a.has_expand ? KP : EP;
     const int64_t img = (int64_t)b * a.H * a.W * K;
-    const int n_in = PIN * vecs, n_w = a.has_expand ? ntiles * 16 * kv : 0;
+    // thread -> (row, vector): vectors rounded up to a power of two so the split is a shift and a mask;
+    // rows = the expand-weight rows c0 .. c0 + 16*ntiles, then the PIN input pixels
+    int vsh = 0; while ((1 << vsh) < vecs) vsh++;
+    const int v = threadIdx.x & ((1 << vsh) - 1), row0 = threadIdx.x >> vsh, rstride = MBF_THREADS >> vsh;
+    const int n_wrows = a.has_expand ? ntiles * 16 : 0, n_rows = n_wrows + PIN;
     const T* Wg = reinterpret_cast<const T*>(a.we) + (int64_t)c0 * K;
-    for (int base = 0; base < ((a.dbg_skip & 1) ? 0 : n_in + n_w); base += MBF_THREADS * NB) {
+    for (int base = 0; base < ((a.dbg_skip & 1) ? 0 : n_rows); base += rstride * NB) {
       raw_t x0[NB], x1[NB];
 #pragma unroll
       for (int j = 0; j < NB; j++) {
-        const int item = base + j * MBF_THREADS + threadIdx.x;
+        const int row = base + j * rstride + row0;
         x0[j] = raw_t{}; x1[j] = raw_t{};
-        if (item < n_w) {                                          // expand-weight rows c0 .. c0 + 16*ntiles
-          const T* src = Wg + (int64_t)(item / kv) * K + (item % kv) * 8;
-          x0[j] = *reinterpret_cast<const raw_t*>(src);
-          if (!BF16) x1[j] = *reinterpret_cast<const raw_t*>(src + 4);
-        } else if (item < n_w + n_in) {
-          const int it = item - n_w, p = it / vecs, v = it % vecs;
-          const int gy = iy0 + p / PW, gx = ix0 + p % PW;
-          if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
-            const T* src = reinterpret_cast<const T*>(a.in) + img + ((int64_t)gy * a.W + gx) * K + cbase + v * 8;
-            x0[j] = *reinterpret_cast<const raw_t*>(src);
-            if (!BF16) x1[j] = *reinterpret_cast<const raw_t*>(src + 4);
+        if (v < vecs && row < n_rows) {
+          const T* src = nullptr;
+          if (row < n_wrows) src = Wg + (int64_t)row * K + v * 8;
+          else {
+            const int p = row - n_wrows;
+            const int gy = iy0 + p / PW, gx = ix0 + p % PW;
+            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) src = reinterpret_cast<const T*>(a.in) + img + ((int64_t)gy * a.W + gx) * K + cbase + v * 8;
           }
+          if (src) { x0[j] = *reinterpret_cast<const raw_t*>(src); if (!BF16) x1[j] = *reinterpret_cast<const raw_t*>(src + 4); }
         }
       }
 #pragma unroll
       for (int j = 0; j < NB; j++) {
-        const int item = base + j * MBF_THREADS + threadIdx.x;
-        raw_t* d = nullptr;
-        if (item < n_w) d = reinterpret_cast<raw_t*>(w_s + (int64_t)(item / kv) * KP + (item % kv) * 8);
-        else if (item < n_w + n_in) { const int it = item - n_w; d = reinterpret_cast<raw_t*>(dst + (int64_t)(it / vecs) * pitch + (it % vecs) * 8); }
-        if (d) { d[0] = x0[j]; if (!BF16) d[1] = x1[j]; }
+        const int row = base + j * rstride + row0;
+        if (v < vecs && row < n_rows) {
+          raw_t* d = row < n_wrows ? reinterpret_cast<raw_t*>(w_s + (int64_t)row * KP + v * 8)
+                                   : reinterpret_cast<raw_t*>(dst + (int64_t)(row - n_wrows) * pitch + v * 8);
+          d[0] = x0[j]; if (!BF16) d[1] = x1[j];
+        }
       }
     }
   }
@@ -114,97 +121,121 @@ __global__ __launch_bounds__(MBF_THREADS) void mbf_kernel(MbfArgs a) {
 
   // ---- phase B: expand 1x1 + bias + swish -> e_s ----
   if (a.has_expand) {
-    const int my_pairs = npairs > wave ? (npairs - wave + MBF_WAVES - 1) / MBF_WAVES : 0;
-    const int my_items = my_pairs * ksteps;
-    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-    auto step = [&](int it, raw_t wfrag) {
-      const int pair = wave + MBF_WAVES * (it / ksteps), ks = it % ksteps;
-      const int mt = pair % mtiles, nt = pair / mtiles;
-      const int m = mt * 16 + r;
-      const int k = ks * KSTEP + KLANE * g;
-      raw_t xa = {};
-      if (k < K && m < PIN) xa = *reinterpret_cast<const raw_t*>(a_s + (int64_t)m * KP + k);
-      if constexpr (BF16) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wfrag), __builtin_bit_cast(bf16x8, xa), acc, 0, 0, 0);
-      } else {
+    // a wave takes TWO m-tiles per weight fragment (one LDS weight read feeds two MFMAs) and keeps
+    // three k-steps of fragments in flight
+    constexpr int mpairs = (mtiles + 1) / 2;
+    for (int pp = wave; pp < ((a.dbg_skip & 2) ? 0 : mpairs * ntiles); pp += MBF_WAVES) {
+      const int nt = pp / mpairs, mp = pp - nt * mpairs;           // mpairs is a compile-time constant
+      const int m0 = mp * 32 + r, m1 = m0 + 16;
+      const T* wrow = w_s + (int64_t)(nt * 16 + r) * KP + KLANE * g;
+      const T* arow0 = a_s + (int64_t)m0 * KP + KLANE * g;
+      const T* arow1 = a_s + (int64_t)m1 * KP + KLANE * g;
+      f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+#pragma unroll 3
+      for (int ks = 0; ks < ksteps; ks++) {
+        const int k = ks * KSTEP + KLANE * g;
+        raw_t wf = {}, xa0 = {}, xa1 = {};
+        if (k < K) {
+          wf = *reinterpret_cast<const raw_t*>(wrow + ks * KSTEP);
+          if (m0 < PIN) xa0 = *reinterpret_cast<const raw_t*>(arow0 + ks * KSTEP);
+          if (m1 < PIN) xa1 = *reinterpret_cast<const raw_t*>(arow1 + ks * KSTEP);
+        }
+        if constexpr (BF16) {
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf), __builtin_bit_cast(bf16x8, xa0), acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf), __builtin_bit_cast(bf16x8, xa1), acc1, 0, 0, 0);
+        } else {
 #pragma unroll
-        for (int q = 0; q < 4; q++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wfrag[q], xa[q], acc, 0, 0, 0);
+          for (int q = 0; q < 4; q++) { acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[q], xa0[q], acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[q], xa1[q], acc1, 0, 0, 0); }
+        }
       }
-      if (ks != ksteps - 1) return;
-      const int n = nt * 16 + 4 * g;          // lane: 4 consecutive expanded channels of tile pixel m
-      if (m < PIN && n < cc) {
-        const int gy = iy0 + m / PW, gx = ix0 + m % PW;
-        const bool inside = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      const int n = nt * 16 + 4 * g;          // lane: 4 consecutive expanded channels of tile pixels m0, m1
+      if (n < cc) {
         const f32x4 bias = *reinterpret_cast<const f32x4*>(be_s + n);
-        float v[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) v[q] = inside ? swish_t<BF16>(acc[q] + bias[q]) : 0.f;
-        V::store4(e_s, (int64_t)m * EP + n, v);
+        for (int half = 0; half < 2; half++) {
+          const int m = half ? m1 : m0;
+          if (m < PIN) {
+            const f32x4 acc = half ? acc1 : acc0;
+            const int gy = iy0 + m / PW, gx = ix0 + m % PW;
+            const bool inside = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            float v[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) v[q] = inside ? swish_t<BF16>(acc[q] + bias[q]) : 0.f;
+            V::store4(e_s, (int64_t)m * EP + n, v);
+          }
+        }
       }
-      acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-    };
-    for (int it = 0; it < ((a.dbg_skip & 2) ? 0 : my_items); it++) {
-      const int pair = wave + MBF_WAVES * (it / ksteps), ks = it % ksteps;
-      const int k = ks * KSTEP + KLANE * g;
-      raw_t wf = {};
-      if (k < K) wf = *reinterpret_cast<const raw_t*>(w_s + (int64_t)((pair / mtiles) * 16 + r) * KP + k);
-      step(it, wf);
     }
     __syncthreads();
   }
 
   // ---- phase C: depthwise taps from LDS -> global, SE sums ----
-  // lane -> (channel group, pixel slot): the channel group of a lane is FIXED (cgs rounded up to a
-  // power of two divides the workgroup), so its squeeze-excite sums stay in registers
+  // A lane owns TWO horizontally adjacent output pixels: their kx windows overlap, so a row of
+  // S + KS input pixels is read (and unpacked) once for both and every weight vector read from LDS
+  // feeds two pixels - this phase is LDS-bandwidth-bound.
   const int cgs = cc >> 3;
-  int cgp = 1; while (cgp < cgs) cgp <<= 1;
-  const int cg = threadIdx.x & (cgp - 1), pslot = threadIdx.x / cgp, pstride = MBF_THREADS / cgp;
+  int cgsh = 0; while ((1 << cgsh) < cgs) cgsh++;
+  const int cgp = 1 << cgsh;
+  const int cg = threadIdx.x & (cgp - 1), pp = threadIdx.x >> cgsh;      // pixel pair 0 .. TS*TS/2 - 1
   float sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (cg < cgs) {
-    float bias[8];
+  if (cg < cgs && pp < TS * TS / 2 && !(a.dbg_skip & 4)) {
+    constexpr int NX = S + KS;
+    const int py = pp / (TS / 2), px = (pp % (TS / 2)) * 2;
+    const int oy = oy0 + py, ox = ox0 + px;
+    float acc0[8], acc1[8];
     {
       const f32x4* bp = reinterpret_cast<const f32x4*>(bdw_s + cg * 8);
       const f32x4 b0 = bp[0], b1 = bp[1];
 #pragma unroll
-      for (int c = 0; c < 4; c++) { bias[c] = b0[c]; bias[4 + c] = b1[c]; }
+      for (int c = 0; c < 4; c++) { acc0[c] = b0[c]; acc0[4 + c] = b1[c]; acc1[c] = b0[c]; acc1[4 + c] = b1[c]; }
     }
-    for (int p = pslot; p < ((a.dbg_skip & 4) ? 0 : TS * TS); p += pstride) {
-      const int py = p / TS, px = p % TS;
-      const int oy = oy0 + py, ox = ox0 + px;
-      float acc[8];
+#pragma unroll 1      // a real loop: unrolled, the compiler hoists all KS*KS weight reads and spills
+    for (int ky = 0; ky < KS; ky++) {
+      float ev[NX][8];
 #pragma unroll
-      for (int c = 0; c < 8; c++) acc[c] = bias[c];
+      for (int j = 0; j < NX; j++) V::load(e_s, (int64_t)((py * S + ky) * PW + px * S + j) * EP + cg * 8, ev[j]);
 #pragma unroll
-      for (int ky = 0; ky < KS; ky++)
+      for (int kx = 0; kx < KS; kx++) {
+        const f32x4* wp = reinterpret_cast<const f32x4*>(wdw_s + (ky * KS + kx) * a.CC + cg * 8);
+        const f32x4 w0 = wp[0], w1 = wp[1];
 #pragma unroll
-        for (int kx = 0; kx < KS; kx++) {
-          float ev[8];
-          V::load(e_s, (int64_t)((py * S + ky) * PW + px * S + kx) * EP + cg * 8, ev);
-          const f32x4* wp = reinterpret_cast<const f32x4*>(wdw_s + (ky * KS + kx) * a.CC + cg * 8);
-          const f32x4 w0 = wp[0], w1 = wp[1];
-#pragma unroll
-          for (int c = 0; c < 4; c++) { acc[c] = fmaf(ev[c], w0[c], acc[c]); acc[4 + c] = fmaf(ev[4 + c], w1[c], acc[4 + c]); }
+        for (int c = 0; c < 4; c++) {
+          acc0[c] = fmaf(ev[kx][c], w0[c], acc0[c]); acc0[4 + c] = fmaf(ev[kx][4 + c], w1[c], acc0[4 + c]);
+          acc1[c] = fmaf(ev[kx + S][c], w0[c], acc1[c]); acc1[4 + c] = fmaf(ev[kx + S][4 + c], w1[c], acc1[4 + c]);
         }
-      if (oy < a.Ho && ox < a.Wo) {
-        float v[8];
+      }
+    }
+    if (oy < a.Ho && ox < a.Wo) {
+      float v[8];
 #pragma unroll
-        for (int c = 0; c < 8; c++) { v[c] = swish_t<BF16>(acc[c]); sum[c] += v[c]; }
-        V::store(a.out, (((int64_t)b * a.Ho + oy) * a.Wo + ox) * a.Cexp + c0 + cg * 8, v);
+      for (int c = 0; c < 8; c++) { v[c] = swish_t<BF16>(acc0[c]); sum[c] += v[c]; }
+      V::store(a.out, (((int64_t)b * a.Ho + oy) * a.Wo + ox) * a.Cexp + c0 + cg * 8, v);
+      if (ox + 1 < a.Wo) {
+#pragma unroll
+        for (int c = 0; c < 8; c++) { v[c] = swish_t<BF16>(acc1[c]); sum[c] += v[c]; }
+        V::store(a.out, (((int64_t)b * a.Ho + oy) * a.Wo + ox + 1) * a.Cexp + c0 + cg * 8, v);
       }
     }
   }
   __syncthreads();      // a_s is dead: reuse as reduction scratch [MBF_THREADS][9]
 
-  // ---- phase D: per-block channel sums, fixed order ----
+  // ---- phase D: per-block channel sums, fixed order: butterfly over the lanes of a wave that share a
+  //      channel group (lane = cg mod cgp), then one LDS row per wave and a sum over the 8 waves ----
   if (a.partial && !(a.dbg_skip & 8)) {
+    for (int off = cgp; off < 64; off <<= 1) {
 #pragma unroll
-    for (int c = 0; c < 8; c++) red[threadIdx.x * 9 + c] = sum[c];
+      for (int c = 0; c < 8; c++) sum[c] += __shfl_xor(sum[c], off, 64);
+    }
+    if (lane < cgs) {            // cgp <= 16 (at most 128 channels per workgroup): lane cg of every wave holds its total
+      f32x4* d = reinterpret_cast<f32x4*>(red + (wave * cgp + lane) * 8);
+      d[0] = (f32x4){sum[0], sum[1], sum[2], sum[3]}; d[1] = (f32x4){sum[4], sum[5], sum[6], sum[7]};
+    }
     __syncthreads();
     const int tiles = tiles_x * ((a.Ho + TS - 1) / TS);
     for (int o = threadIdx.x; o < cc; o += MBF_THREADS) {
-      const int ocg = o >> 3, oc = o & 7;
       float s = 0.f;
-      for (int t = ocg; t < MBF_THREADS; t += cgp) s += red[t * 9 + oc];     // lane t owns channel group t % cgp
+#pragma unroll
+      for (int w8 = 0; w8 < MBF_WAVES; w8++) s += red[(w8 * cgp + (o >> 3)) * 8 + (o & 7)];
       a.partial[((int64_t)b * tiles + tile) * a.Cexp + c0 + o] = s;
     }
   }
