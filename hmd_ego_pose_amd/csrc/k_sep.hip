@@ -148,54 +148,55 @@ __global__ __launch_bounds__(SEP_THREADS_OF(MODE), MODE == 1 ? SEP_M1_WAVES : 4)
   float* wdw_s = reinterpret_cast<float*>(smem + a.off_wdw);
   float* bias_s = reinterpret_cast<float*>(smem + a.off_bias);
 
-  // ---- phase 0: weight prefetch (independent of the activations) ----
+  // (index arithmetic below: channel groups and tile sides are split with shifts and masks, the halo
+  //  side with a compile-time divisor per tile size - a run-time integer division costs ~30 VALU
+  //  instructions and this kernel used to issue half a dozen of them per work item)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, g = lane >> 4;
   const int rows_valid = min(TS, h - y0), cols_valid = min(TS, w - x0);
   const int mtv = TS == 16 ? rows_valid : (rows_valid + 1) >> 1;   // 16-pixel m-tiles holding a valid pixel
   const int ksteps = (C + KSTEP - 1) / KSTEP;
-  const int npairs = mtv * sg.tilesN;                              // pair = nt * mtv + mt
   const T* W = reinterpret_cast<const T*>(sg.wpw);
-  auto wload = [&](int it) -> raw_t {                              // it = this wave's it-th (pair, kstep)
-    raw_t v = {};
-    const int pair = wave + SEP_WAVES * (it / ksteps), ks = it % ksteps;
-    const int k = ks * KSTEP + KLANE * g;
-    if (pair < npairs && k < C) v = *reinterpret_cast<const raw_t*>(W + (int64_t)((pair / mtv) * 16 + r) * C + k);
-    return v;
-  };
-  raw_t wring[4];
-#pragma unroll
-  for (int q = 0; q < 4; q++) wring[q] = wload(q);
+  int cgsh = 0; while ((1 << cgsh) < CG) cgsh++;
+  const int tssh = TS == 16 ? 4 : 3;
+  // ---- phase 0: depthwise weights + bias to LDS (independent of the activations) ----
   for (int i = threadIdx.x; i < 9 * C; i += SEP_THREADS) wdw_s[i] = sg.wdw[i];
   for (int i = threadIdx.x; i < sg.tilesN * 16; i += SEP_THREADS) bias_s[i] = sg.bias[i];
 
   // ---- phase 1: fused (+swish) halo of the depthwise input, zero outside the image ----
-  for (int item = threadIdx.x; item < ((a.dbg_skip & 1) ? 0 : HS * HS * CG); item += SEP_THREADS) {
-    const int pos = item / CG, cg = item % CG;
-    const int y = y0 + pos / HS - 1, x = x0 + pos % HS - 1;
-    float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (y >= 0 && y < h && x >= 0 && x < w) gather_fuse<BF16>(sg, b, y, x, cg * 8, v);
-    V::store(halo, (int64_t)pos * CH + cg * 8, v);
+  {
+    const int cg = threadIdx.x & ((1 << cgsh) - 1);
+    if (cg < CG)
+      for (int pos = threadIdx.x >> cgsh; pos < ((a.dbg_skip & 1) ? 0 : HS * HS); pos += SEP_THREADS >> cgsh) {
+        const int hy = TS == 16 ? pos / 18 : pos / 10, hx = pos - hy * HS;
+        const int y = y0 + hy - 1, x = x0 + hx - 1;
+        float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (y >= 0 && y < h && x >= 0 && x < w) gather_fuse<BF16>(sg, b, y, x, cg * 8, v);
+        V::store(halo, (int64_t)pos * CH + cg * 8, v);
+      }
   }
   __syncthreads();
 
   // ---- phase 2: depthwise 3x3 -> operand tile [TS*TS pixels][C] ----
-  for (int item = threadIdx.x; item < ((a.dbg_skip & 2) ? 0 : TS * TS * CG); item += SEP_THREADS) {
-    const int p = item / CG, cg = item % CG;
-    const int py = p / TS, px = p % TS;
-    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  {
+    const int cg = threadIdx.x & ((1 << cgsh) - 1);
+    if (cg < CG)
+      for (int p = threadIdx.x >> cgsh; p < ((a.dbg_skip & 2) ? 0 : TS * TS); p += SEP_THREADS >> cgsh) {
+        const int py = p >> tssh, px = p & (TS - 1);
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-    for (int ky = 0; ky < 3; ky++)
+        for (int ky = 0; ky < 3; ky++)
 #pragma unroll
-      for (int kx = 0; kx < 3; kx++) {
-        float hv[8];
-        V::load(halo, (int64_t)((py + ky) * HS + px + kx) * CH + cg * 8, hv);
-        const f32x4* wp = reinterpret_cast<const f32x4*>(wdw_s + (ky * 3 + kx) * C + cg * 8);
-        const f32x4 w0 = wp[0], w1 = wp[1];
+          for (int kx = 0; kx < 3; kx++) {
+            float hv[8];
+            V::load(halo, (int64_t)((py + ky) * HS + px + kx) * CH + cg * 8, hv);
+            const f32x4* wp = reinterpret_cast<const f32x4*>(wdw_s + (ky * 3 + kx) * C + cg * 8);
+            const f32x4 w0 = wp[0], w1 = wp[1];
 #pragma unroll
-        for (int c = 0; c < 4; c++) { acc[c] = fmaf(hv[c], w0[c], acc[c]); acc[4 + c] = fmaf(hv[4 + c], w1[c], acc[4 + c]); }
+            for (int c = 0; c < 4; c++) { acc[c] = fmaf(hv[c], w0[c], acc[c]); acc[4 + c] = fmaf(hv[4 + c], w1[c], acc[4 + c]); }
+          }
+        V::store(atile, (int64_t)p * CH + cg * 8, acc);
       }
-    V::store(atile, (int64_t)p * CH + cg * 8, acc);
   }
   __syncthreads();      // halo is dead from here on: its LDS becomes the output tile
 
@@ -203,23 +204,26 @@ __global__ __launch_bounds__(SEP_THREADS_OF(MODE), MODE == 1 ? SEP_M1_WAVES : 4)
   const int Nc = sg.N;                                    // columns of this segment
   float* otile_f = reinterpret_cast<float*>(smem);        // [TS*TS][Nc] fp32 (head outputs)
   T* otile_t = reinterpret_cast<T*>(smem);                // [TS*TS][Nc] dtype (maps)
-  const int my_pairs = npairs > wave ? (npairs - wave + SEP_WAVES - 1) / SEP_WAVES : 0;
-  const int my_items = my_pairs * ksteps;
-  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-  auto step = [&](int it, raw_t wfrag) {
-    const int pair = wave + SEP_WAVES * (it / ksteps), ks = it % ksteps;
-    const int mt = pair % mtv, nt = pair / mtv;
+  // (m-tile, n-tile) pairs are dealt round-robin to the waves; pair -> (nt, mt) is a shift and a mask
+  int mtsh = 0; while ((1 << mtsh) < mtv) mtsh++;
+  for (int pair = wave; pair < ((a.dbg_skip & 4) ? 0 : sg.tilesN << mtsh); pair += SEP_WAVES) {
+    const int nt = pair >> mtsh, mt = pair & ((1 << mtsh) - 1);
+    if (mt >= mtv) continue;
     const int m = mt * 16 + r;
-    const int k = ks * KSTEP + KLANE * g;
-    raw_t xa = {};
-    if (k < C) xa = *reinterpret_cast<const raw_t*>(atile + (int64_t)m * CH + k);
-    if constexpr (BF16) {
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wfrag), __builtin_bit_cast(bf16x8, xa), acc, 0, 0, 0);
-    } else {
+    const T* wrow = W + (int64_t)(nt * 16 + r) * C + KLANE * g;
+    const T* arow = atile + (int64_t)m * CH + KLANE * g;
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int ks = 0; ks < ksteps; ks++) {
+      raw_t wf = {}, xa = {};
+      if (ks * KSTEP + KLANE * g < C) { wf = *reinterpret_cast<const raw_t*>(wrow + ks * KSTEP); xa = *reinterpret_cast<const raw_t*>(arow + ks * KSTEP); }
+      if constexpr (BF16) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf), __builtin_bit_cast(bf16x8, xa), acc, 0, 0, 0);
+      } else {
 #pragma unroll
-      for (int q = 0; q < 4; q++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wfrag[q], xa[q], acc, 0, 0, 0);
+        for (int q = 0; q < 4; q++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[q], xa[q], acc, 0, 0, 0);
+      }
     }
-    if (ks != ksteps - 1) return;
     const int n = nt * 16 + 4 * g;          // lane: 4 consecutive columns of pixel m
     if (n < Nc) {
       const f32x4 bias = *reinterpret_cast<const f32x4*>(bias_s + n);
@@ -231,17 +235,6 @@ __global__ __launch_bounds__(SEP_THREADS_OF(MODE), MODE == 1 ? SEP_M1_WAVES : 4)
         for (int q = 0; q < 4; q++) if (n + q < Nc) otile_f[(int64_t)m * Nc + n + q] = v[q];
       } else {
         V::store4(otile_t, (int64_t)m * Nc + n, v);     // Nc is a multiple of 8 for every map-producing layer
-      }
-    }
-    acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-  };
-  for (int it = 0; it < ((a.dbg_skip & 4) ? 0 : my_items); it += 4) {
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      if (it + q < my_items) {
-        const raw_t wf = wring[q];
-        wring[q] = wload(it + q + 4);       // refill the slot 4 items ahead (zero past the end)
-        step(it + q, wf);
       }
     }
   }
@@ -267,14 +260,17 @@ __global__ __launch_bounds__(SEP_THREADS_OF(MODE), MODE == 1 ? SEP_M1_WAVES : 4)
     // write consecutive 16-byte vectors of a pixel, then the next pixel of the tile row
     T* o = reinterpret_cast<T*>(sg.out) + (int64_t)b * sg.out_bstride + sg.out_off;
     const int vpp = Nc >> 3;
-    for (int idx = threadIdx.x; idx < rows_valid * cols_valid * vpp; idx += SEP_THREADS) {
-      const int pix = idx / vpp, cv = idx % vpp;
-      const int py = pix / cols_valid, px = pix % cols_valid;
-      const unsigned char* src = reinterpret_cast<const unsigned char*>(otile_t) + ((int64_t)(py * TS + px) * Nc + cv * 8) * sizeof(T);
-      T* dst = o + ((int64_t)(y0 + py) * w + x0 + px) * sg.out_rowstride + cv * 8;
-      *reinterpret_cast<u32x4*>(dst) = *reinterpret_cast<const u32x4*>(src);
-      if constexpr (!BF16) *reinterpret_cast<u32x4*>(dst + 4) = *reinterpret_cast<const u32x4*>(src + 16);
-    }
+    int vsh = 0; while ((1 << vsh) < vpp) vsh++;
+    const int cv = threadIdx.x & ((1 << vsh) - 1);
+    if (cv < vpp)
+      for (int pix = threadIdx.x >> vsh; pix < TS * TS; pix += SEP_THREADS >> vsh) {
+        const int py = pix >> tssh, px = pix & (TS - 1);
+        if (py >= rows_valid || px >= cols_valid) continue;
+        const unsigned char* src = reinterpret_cast<const unsigned char*>(otile_t) + ((int64_t)pix * Nc + cv * 8) * sizeof(T);
+        T* dst = o + ((int64_t)(y0 + py) * w + x0 + px) * sg.out_rowstride + cv * 8;
+        *reinterpret_cast<u32x4*>(dst) = *reinterpret_cast<const u32x4*>(src);
+        if constexpr (!BF16) *reinterpret_cast<u32x4*>(dst + 4) = *reinterpret_cast<const u32x4*>(src + 16);
+      }
   }
   // chain mode: this node's stores must have landed (and every LDS reader be done) before the next
   // node of the chain gathers them - same workgroup, same CU, so a barrier after vmcnt(0) suffices
