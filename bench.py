@@ -75,6 +75,25 @@ def cpu_baseline(phi, size, budget_s=15.0):
                       f"forward + anchors + box/translation decode, {el:.1f} s, best of 8..128 torch threads on {os.cpu_count()} host CPUs"}
 
 
+def pmc_traffic(symbol):
+    """HBM bytes per launch of `symbol` from the newest committed PMC pass (profiles/r*/*_pmc_per_kernel.json:
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, KB per launch).  gfx950 correction from
+    /opt/skills/guides/MI355X_MICROARCH.md: FETCH_SIZE counts 128-byte requests as 64 bytes, so reads are
+    doubled; WRITE_SIZE is exact for 16-byte stores.  None when no pass holds the kernel."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "*_pmc_per_kernel.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+            rd, wr = d["FETCH_SIZE"].get(symbol), d["WRITE_SIZE"].get(symbol)
+            if rd and wr:
+                return {"bytes_per_launch": round((2.0 * rd["KB_per_launch"] + wr["KB_per_launch"]) * 1024),
+                        "read_bytes": round(2.0 * rd["KB_per_launch"] * 1024), "write_bytes": round(wr["KB_per_launch"] * 1024),
+                        "source": os.path.relpath(f, ROOT)}
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -165,14 +184,9 @@ def main():
                 step(i, 1)
             torch.cuda.synchronize(dev); e1 = time.perf_counter() - t1
             out["one_batch_in_flight"] = {"value": round(B * k1 / e1, 2), "ms_per_step": round(e1 / k1 * 1e3, 4)}
-            # per-launch durations under the SAME load as the timed region: slots 1..D-1 keep replaying their
-            # forwards in the background while slot 0 is profiled with HIP events on its own stream
-            bg = int(60 * ms / 0.7) if D > 1 else 0
-            for r in range(bg):
-                for d in range(1, D):
-                    _capi.check(lib.hep_run_device(sess[d].handle, xs[d].data_ptr(), strides, B, None, None, streams[d].cuda_stream))
+            # per-launch durations: one batch in flight (the only regime in which a launch can be timed alone;
+            # with several batches in flight launches of different batches overlap on the chip)
             total_ms, per = sess[0].profile(B, 20, per_kernel=True)
-            still_loaded = any(not st.query() for st in streams[1:]) if D > 1 else True
             torch.cuda.synchronize(dev)
             ks = sess[0].kernels(B)
             # per-launch durations come from an eager pass with a HIP event in front of every launch; the
@@ -188,11 +202,11 @@ def main():
             achieved = nbytes / (t * 1e-3) / 1e9
             step_bytes = sum(k[1] for k in ks)
             out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                               "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(sym),
                                "kernel": sym, "launches_per_step": calls, "avg_launch_us": round(t / calls * 1e3, 2),
                                "algorithmic_bytes_per_launch": round(nbytes / calls), "share_of_step": round(t / sum(per), 3),
-                               "measured_with_batches_in_flight": D if still_loaded else 1,
-                               "graph_replay_ms_under_load": round(total_ms, 4), "event_overhead_us_subtracted": round(ev_overhead * 1e3, 2),
+                               "measured_with_batches_in_flight": 1,
+                               "graph_replay_ms": round(total_ms, 4), "event_overhead_us_subtracted": round(ev_overhead * 1e3, 2),
                                "whole_step_algorithmic_GBps": round(step_bytes / (ms * 1e-3) / 1e9, 1),
                                "end_to_end_frac": round(step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
             if not args.no_cpu_baseline:

@@ -37,6 +37,7 @@ struct DwArgs {
   const void* in; const float* w /*[k*k][C]*/; const float* bias; void* out;
   float* partial;      // [B][blocks_per_image][C] (nullable)
   int B, H, W, C, Ho, Wo, k, s, pad_t, pad_l, act, bf16, TW, blocks_per_image;
+  uint32_t cg_magic, sw_magic, c_magic;   // reciprocals for C/8, strips per row and C (filled in by launch_dw)
 };
 
 // ---- squeeze-excite FCs: mean -> reduce(+swish) -> expand(+sigmoid) ----

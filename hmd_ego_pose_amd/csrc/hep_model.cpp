@@ -605,11 +605,11 @@ int build_session(Session* s, const Pack& pack, std::string* err) {
       for (int l = 0; l < 5; l++) { in[l] = feat[l]; in2[l] = feat[l]; }
     }
     float w[3];
-    // Consecutive nodes on levels <= 8x8 (one tile per image) can be launched as ONE chain: a workgroup
-    // per image runs them back to back (k_sep.hip mode 2).
-    // Measured: a 5-node chain takes 44 us, the same as five launches (each node is ~8 us of serialized
-    // global round trips with or without a kernel boundary), so chains are OFF by default (HEP_CHAIN=1).
-    static const bool chain_on = getenv("HEP_CHAIN") && atoi(getenv("HEP_CHAIN")) != 0;
+    // Consecutive nodes on levels <= 8x8 (one tile per image) are launched as ONE chain: a workgroup
+    // per image runs them back to back (k_sep.hip mode 2).  Measured at bs16: a 5-node chain takes
+    // 29.8 us against 5 x 7 us as separate launches (a node is ~6 us of dependent global round trips
+    // inside the kernel either way; the chain saves the launch boundaries).  HEP_CHAIN=0 disables it.
+    static const bool chain_on = !(getenv("HEP_CHAIN") && atoi(getenv("HEP_CHAIN")) == 0);
     auto flush = [&]() {
       if (pending.empty()) return;
       std::string nm = pending_names.front();

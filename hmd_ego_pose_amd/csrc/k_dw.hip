@@ -75,20 +75,31 @@ void launch_stem(const StemArgs& a, hipStream_t s) {
 // Squeeze-excite: each lane sums its post-swish outputs, the block reduces them through LDS in a
 // FIXED order and writes partial[b][block][c] - no atomics, so the result is bit-reproducible.
 // ------------------------------------------------------------------------------------------------
+// exact x / d for x * d < 2^32 with m = floor(2^32 / d) + 1 (two VALU instructions instead of ~30)
+__device__ __forceinline__ int fast_div(int x, uint32_t m) { return (int)__umulhi((uint32_t)x, m); }
+
 template <bool BF16, int KS, int S, int TW>
 __global__ __launch_bounds__(256) void dw_kernel(DwArgs a) {
   typedef Vec8<BF16> V;
-  __shared__ float red[256][9];
+  extern __shared__ __attribute__((aligned(16))) float dw_smem[];
+  float* w_s = dw_smem;                         // [KS*KS][C] weights, then [C] bias
+  float (*red)[9] = reinterpret_cast<float (*)[9]>(dw_smem + (KS * KS + 1) * a.C);
   const int CG = a.C >> 3;
   const int SW = (a.Wo + TW - 1) / TW;
   const int nitems = a.Ho * SW * CG;
   const int item = blockIdx.x * 256 + threadIdx.x;
   const int b = blockIdx.y;
   const bool valid = item < nitems;
-  const int cg = valid ? item % CG : 0;
-  const int strip = valid ? item / CG : 0;
-  const int oy = strip / SW, ox0 = (strip % SW) * TW;
+  const int strip = valid ? fast_div(item, a.cg_magic) : 0;
+  const int cg = valid ? item - strip * CG : 0;
+  const int oy = fast_div(strip, a.sw_magic), ox0 = (strip - oy * SW) * TW;
   constexpr int WIN = (TW - 1) * S + KS;
+
+  // every lane needs the K*K weight vectors of its channel group: staged in LDS once per workgroup
+  // (as global loads they were half of all vector-memory instructions of the kernel)
+  for (int i = threadIdx.x; i < (KS * KS * a.C) >> 2; i += 256) reinterpret_cast<f32x4*>(w_s)[i] = reinterpret_cast<const f32x4*>(a.w)[i];
+  for (int i = threadIdx.x; i < a.C >> 2; i += 256) reinterpret_cast<f32x4*>(w_s + KS * KS * a.C)[i] = reinterpret_cast<const f32x4*>(a.bias)[i];
+  __syncthreads();
 
   float acc[TW][8];
 #pragma unroll
@@ -106,7 +117,7 @@ __global__ __launch_bounds__(256) void dw_kernel(DwArgs a) {
       float w[KS][8];
 #pragma unroll
       for (int kx = 0; kx < KS; kx++) {
-        const f32x4* wp = reinterpret_cast<const f32x4*>(a.w + (ky * KS + kx) * a.C + cg * 8);
+        const f32x4* wp = reinterpret_cast<const f32x4*>(w_s + (ky * KS + kx) * a.C + cg * 8);
         f32x4 w0 = wp[0], w1 = wp[1];
 #pragma unroll
         for (int c = 0; c < 4; c++) { w[kx][c] = w0[c]; w[kx][4 + c] = w1[c]; }
@@ -120,7 +131,6 @@ __global__ __launch_bounds__(256) void dw_kernel(DwArgs a) {
 #pragma unroll
         for (int kx = 0; kx < KS; kx++) {
           if ((c0 - kx) % S != 0 || c0 - kx < 0) continue;
-          constexpr int dummy = 0; (void)dummy;
           const int p = (c0 - kx) / S;
           if (p >= TW) continue;
 #pragma unroll
@@ -130,7 +140,7 @@ __global__ __launch_bounds__(256) void dw_kernel(DwArgs a) {
     }
     float bias[8];
     {
-      const f32x4* bp = reinterpret_cast<const f32x4*>(a.bias + cg * 8);
+      const f32x4* bp = reinterpret_cast<const f32x4*>(w_s + KS * KS * a.C + cg * 8);
       f32x4 b0 = bp[0], b1 = bp[1];
 #pragma unroll
       for (int c = 0; c < 4; c++) { bias[c] = b0[c]; bias[4 + c] = b1[c]; }
@@ -147,16 +157,32 @@ __global__ __launch_bounds__(256) void dw_kernel(DwArgs a) {
   }
 
   if (a.partial) {   // deterministic per-block channel sums for the squeeze-excite mean
+    // thread t owns channel group (first_item + t) % CG.  Two steps, both in a fixed order: G = 256 / C
+    // helper groups each add every G-th contribution of a channel, then the G helpers are added up.
 #pragma unroll
     for (int c = 0; c < 8; c++) red[threadIdx.x][c] = sum[c];
     __syncthreads();
-    const int first_item = blockIdx.x * 256;
-    for (int o = threadIdx.x; o < CG * 8; o += 256) {
+    const int C = CG * 8, G = max(1, 256 / C);
+    const int first_cg = blockIdx.x * 256 - fast_div(blockIdx.x * 256, a.cg_magic) * CG;   // channel group of thread 0
+    float part = 0.f;
+    const int gq = fast_div(threadIdx.x, a.c_magic), o = threadIdx.x - gq * C;            // helper group, channel
+    if (gq < G) {
       const int ocg = o >> 3, oc = o & 7;
-      int t = (ocg - first_item % CG + CG) % CG;    // first thread of this block owning channel group ocg
-      float s = 0.f;
-      for (; t < 256; t += CG) s += red[t][oc];
-      a.partial[((int64_t)b * a.blocks_per_image + blockIdx.x) * a.C + o] = s;
+      int t = ocg - first_cg; if (t < 0) t += CG;          // first thread of this block owning channel group ocg
+      for (t += gq * CG; t < 256; t += G * CG) part += red[t][oc];
+    }
+    __syncthreads();
+    if (gq < G) red[threadIdx.x][8] = part;
+    __syncthreads();
+    for (int oo = threadIdx.x; oo < C; oo += 256) {
+      float s_ = 0.f;
+      if (C <= 256) { for (int q = 0; q < G; q++) s_ += red[q * C + oo][8]; }
+      else {                                             // more channels than threads: no helpers, walk directly
+        const int ocg = oo >> 3, oc = oo & 7;
+        int t = ocg - first_cg; if (t < 0) t += CG;
+        for (; t < 256; t += CG) s_ += red[t][oc];
+      }
+      a.partial[((int64_t)b * a.blocks_per_image + blockIdx.x) * a.C + oo] = s_;
     }
   }
 }
@@ -168,10 +194,11 @@ int dw_blocks_per_image(int Ho, int Wo, int C, int TW) {
 
 template <bool BF16, int KS, int S>
 static void launch_dw_tw(const DwArgs& a, dim3 grid, hipStream_t s) {
+  const size_t lds = ((size_t)(KS * KS + 1) * a.C + 256 * 9) * sizeof(float);
   switch (a.TW) {
-    case 1: hipLaunchKernelGGL((dw_kernel<BF16, KS, S, 1>), grid, dim3(256), 0, s, a); break;
-    case 2: hipLaunchKernelGGL((dw_kernel<BF16, KS, S, 2>), grid, dim3(256), 0, s, a); break;
-    default: hipLaunchKernelGGL((dw_kernel<BF16, KS, S, 4>), grid, dim3(256), 0, s, a); break;
+    case 1: hipLaunchKernelGGL((dw_kernel<BF16, KS, S, 1>), grid, dim3(256), lds, s, a); break;
+    case 2: hipLaunchKernelGGL((dw_kernel<BF16, KS, S, 2>), grid, dim3(256), lds, s, a); break;
+    default: hipLaunchKernelGGL((dw_kernel<BF16, KS, S, 4>), grid, dim3(256), lds, s, a); break;
   }
 }
 template <bool BF16>
@@ -181,7 +208,11 @@ static void launch_dw_t(const DwArgs& a, dim3 grid, hipStream_t s) {
   else if (a.k == 5 && a.s == 1) launch_dw_tw<BF16, 5, 1>(a, grid, s);
   else launch_dw_tw<BF16, 5, 2>(a, grid, s);
 }
-void launch_dw(const DwArgs& a, hipStream_t s) {
+void launch_dw(const DwArgs& a_, hipStream_t s) {
+  DwArgs a = a_;
+  const uint32_t CG = (uint32_t)a.C >> 3, SW = (uint32_t)(a.Wo + a.TW - 1) / a.TW;
+  a.cg_magic = (uint32_t)(0x100000000ull / CG) + 1; a.sw_magic = (uint32_t)(0x100000000ull / SW) + 1;
+  a.c_magic = (uint32_t)(0x100000000ull / (uint32_t)a.C) + 1;
   dim3 grid(a.blocks_per_image, a.B);
   if (a.bf16) launch_dw_t<true>(a, grid, s); else launch_dw_t<false>(a, grid, s);
 }
