@@ -16,8 +16,8 @@
 //   2. maps:    D[n, pixel] = W . X^T  (weights as A operand): a lane ends with 4 consecutive
 //               channels of one pixel; the planner permutes the weight rows so that two n-tiles give
 //               8 consecutive channels -> one 16-byte store straight to the NHWC map,
-//      headers: D[pixel, n] = X . W^T  (pixels as A operand): 16 consecutive lanes hold 16
-//               consecutive columns of a pixel -> 64-byte runs of the [B, N_anchors, K] result.
+//      headers: the same product; a lane's 4 consecutive columns of its pixel leave as one 16-byte
+//               store into the [B, N_anchors, K] result (4-byte aligned: rows are 9*K floats).
 // LDS holds the depthwise weights + bias (one barrier) and a wave-private slot for the finished
 // operand fragments.
 #include <stdlib.h>
@@ -93,6 +93,7 @@ template <> struct Frag<false> {
 // LDS layout of one workgroup (4 waves), shared with tower_lds_bytes():
 //   [9*CW] f32 depthwise weights | [TOWER_BIAS_MAX] f32 bias | 4 waves x KS x 64 lanes operand fragments
 //   | (when it fits in 48 KB) the segment's pointwise weights, rows padded against bank conflicts
+//   | (when they fit in 40 KB) the 6x6-pixel input halos of the 4 waves
 template <bool BF16, int CW, bool HDR> struct TowerCfg {
   static constexpr int ES = BF16 ? 2 : 4;
   static constexpr int KL = BF16 ? 8 : 4, KSTEP = 4 * KL, KS = (CW + KSTEP - 1) / KSTEP;
@@ -100,9 +101,12 @@ template <bool BF16, int CW, bool HDR> struct TowerCfg {
   static constexpr int WROWS = (HDR ? TOWER_HDR_TILES : NTMAP) * 16;  // most weight rows a segment has
   static constexpr int WP = CW + (BF16 ? 8 : 4);                      // LDS row pitch (elements)
   static constexpr bool WLDS = (size_t)WROWS * WP * ES <= 48 * 1024;
+  static constexpr int HP = CW + 16 / ES;                             // halo pixel pitch (elements): +16 bytes
+  static constexpr bool HALO = (size_t)4 * 36 * HP * ES <= 40 * 1024;  // the 6x6-pixel halos of 4 waves fit
   static constexpr size_t OFF_XA = ((size_t)9 * CW + TOWER_BIAS_MAX) * 4;
   static constexpr size_t OFF_W = OFF_XA + (size_t)4 * KS * 64 * 16;
-  static constexpr size_t LDS = OFF_W + (WLDS ? (size_t)WROWS * WP * ES : 0);
+  static constexpr size_t OFF_HALO = OFF_W + (WLDS ? (size_t)WROWS * WP * ES : 0);
+  static constexpr size_t LDS = OFF_HALO + (HALO ? (size_t)4 * 36 * HP * ES : 0);
 };
 
 template <bool BF16, int CW, bool HDR>
@@ -169,29 +173,61 @@ __global__ __launch_bounds__(256, BF16 ? 4 : 2) void tower_kernel(const SepSeg* 
   const bool pix_ok = y < h && x < w;
 
   // ---- depthwise 3x3 in registers: lane = (pixel r, channels ks*KSTEP + KL*g ..) ----
-  // taps are raw buffer loads of one image: a tap in the SAME padding (or of a lane without a pixel)
-  // gets an out-of-range offset and the hardware returns zeros - no branches, no masking
+  // Input pixels arrive by raw buffer loads of one image: anything in the SAME padding (or belonging to a
+  // lane without a pixel) gets an out-of-range offset and the hardware returns zeros - no branches, no
+  // masking.  Two ways to get the 9 taps into the MFMA lane layout:
+  //   HALO  the wave's 6x6-pixel halo is fetched once with fully coalesced 16-byte lanes (consecutive
+  //         lanes = consecutive channels of a pixel) into a wave-private LDS block and the taps are LDS
+  //         reads.  In the MFMA layout consecutive lanes are different PIXELS, so direct tap loads touch
+  //         four cache lines per quad and were measured ~1.6x slower through the texture addresser.
+  //   else  (wide layers whose halos do not fit) the taps are loaded straight into registers.
+  constexpr bool HALO = Cfg::HALO;
+  constexpr int HP = Cfg::HP, CPP = CW / KL, NV = HALO ? (36 * CPP + 63) / 64 : 1;
   const int img_elems = h * w * CW;
   const GLOBAL T* X0 = (const GLOBAL T*)sg->src[0] + (int64_t)b0 * img_elems;
   constexpr uint32_t OOB = 0x80000000u;
-  uint32_t toff[9];
+  T* halo = reinterpret_cast<T*>(smem + Cfg::OFF_HALO) + wave * 36 * HP;
+  uint32_t toff[9];                    // direct taps: byte offsets; HALO: LDS element offsets of the 9 taps
+  uint32_t hoff[NV]; int hdst[NV];     // HALO: this lane's vectors of the halo (global byte offset, LDS element offset)
+  raw_t hv[NV];
+  if constexpr (HALO) {
 #pragma unroll
-  for (int q = 0; q < 9; q++) {
-    const int iy = y + q / 3 - 1, ix = x + q % 3 - 1;
-    const bool ok = pix_ok && iy >= 0 && iy < h && ix >= 0 && ix < w;
-    toff[q] = ok ? (uint32_t)((iy * w + ix) * CW + KL * g) * ES : OOB;
+    for (int j = 0; j < NV; j++) {
+      const int v = lane + 64 * j, hp = v / CPP, ch = v - hp * CPP;     // halo slot hp = hx * 6 + hy (column-major:
+      const int hx = hp / 6, hy = hp - hx * 6;                          //  conflict-free tap reads with the 16-byte pad)
+      const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+      const bool ok = v < 36 * CPP && iy >= 0 && iy < h && ix >= 0 && ix < w;
+      hoff[j] = ok ? (uint32_t)((iy * w + ix) * CW + ch * KL) * ES : OOB;
+      hdst[j] = v < 36 * CPP ? hp * HP + ch * KL : -1;
+    }
+#pragma unroll
+    for (int q = 0; q < 9; q++) toff[q] = (uint32_t)((((r & 3) + q % 3) * 6 + (r >> 2) + q / 3) * HP + KL * g);
+  } else {
+#pragma unroll
+    for (int q = 0; q < 9; q++) {
+      const int iy = y + q / 3 - 1, ix = x + q % 3 - 1;
+      const bool ok = pix_ok && iy >= 0 && iy < h && ix >= 0 && ix < w;
+      toff[q] = ok ? (uint32_t)((iy * w + ix) * CW + KL * g) * ES : OOB;
+    }
   }
   raw_t tp[G][9];
   auto load_group = [&](int bi, int gi) {
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)(X0 + (int64_t)bi * img_elems), 0, img_elems * ES, 0x00020000);
+    if constexpr (HALO) {
+      if (gi == 0) {
 #pragma unroll
-    for (int j = 0; j < G; j++) {
-      const int ks = gi * G + j;
-      if (ks < KS) {
-        const bool kok = KFULL || ks * KSTEP + KL * g < CW;
+        for (int j = 0; j < NV; j++) hv[j] = __builtin_bit_cast(raw_t, __builtin_amdgcn_raw_buffer_load_b128(xrs, hoff[j], 0, 0));
+      }
+    } else {
 #pragma unroll
-        for (int q = 0; q < 9; q++)
-          tp[j][q] = __builtin_bit_cast(raw_t, __builtin_amdgcn_raw_buffer_load_b128(xrs, kok ? toff[q] : OOB, ks * KSTEP * ES, 0));
+      for (int j = 0; j < G; j++) {
+        const int ks = gi * G + j;
+        if (ks < KS) {
+          const bool kok = KFULL || ks * KSTEP + KL * g < CW;
+#pragma unroll
+          for (int q = 0; q < 9; q++)
+            tp[j][q] = __builtin_bit_cast(raw_t, __builtin_amdgcn_raw_buffer_load_b128(xrs, kok ? toff[q] : OOB, ks * KSTEP * ES, 0));
+        }
       }
     }
   };
@@ -218,6 +254,15 @@ __global__ __launch_bounds__(256, BF16 ? 4 : 2) void tower_kernel(const SepSeg* 
 #pragma unroll 1
   for (int bi = 0; bi < nimg; bi++) {
   const int b = b0 + bi;
+  if constexpr (HALO) {
+    // park this image's halo (the previous image's tap reads are done: LDS executes a wave in order),
+    // then put the next image's halo in flight
+    if (!(dbg & 2)) {
+#pragma unroll
+      for (int j = 0; j < NV; j++) if (hdst[j] >= 0) *reinterpret_cast<raw_t*>(halo + hdst[j]) = hv[j];
+      if (bi + 1 < nimg) load_group(bi + 1, 0);
+    }
+  }
 #pragma unroll 1
   for (int gi = 0; gi < ((dbg & 2) ? 0 : NG); gi++) {
 #pragma unroll
@@ -225,17 +270,23 @@ __global__ __launch_bounds__(256, BF16 ? 4 : 2) void tower_kernel(const SepSeg* 
       const int ks = gi * G + j;
       if (ks < KS) {
         const int k = ks * KSTEP + KL * g;
-        const float* wl = wdw_s + ((KFULL || k < CW) ? k : 0);
+        const bool kok = KFULL || k < CW;
+        const float* wl = wdw_s + (kok ? k : 0);
         typename F::Acc acc;
         F::zero(acc);
 #pragma unroll
-        for (int q = 0; q < 9; q++) F::fma_tap(acc, tp[j][q], wl + q * CW);
-        xa_s[ks * 64] = F::pack(acc);
+        for (int q = 0; q < 9; q++) {
+          if constexpr (HALO) F::fma_tap(acc, *reinterpret_cast<const raw_t*>(halo + toff[q] + (kok ? ks * KSTEP : 0)), wl + q * CW);
+          else F::fma_tap(acc, tp[j][q], wl + q * CW);
+        }
+        raw_t xv = F::pack(acc);
+        if (HALO && !KFULL && !kok) xv = raw_t{};      // k >= CW: the operand must be exactly zero
+        xa_s[ks * 64] = xv;
       }
     }
-    if (gi + 1 < NG) load_group(bi, gi + 1);
+    if (!HALO && gi + 1 < NG) load_group(bi, gi + 1);
   }
-  if (bi + 1 < nimg && !(dbg & 2)) load_group(bi + 1, 0);     // next image's taps fly during the MFMA phase
+  if (!HALO && bi + 1 < nimg && !(dbg & 2)) load_group(bi + 1, 0);     // next image's taps fly during the MFMA phase
   TSTAMP_NOWAIT(4);                    // depthwise done (fragments in LDS)
   if (dbg & 4) continue;
   if constexpr (!HDR) {
@@ -277,22 +328,19 @@ __global__ __launch_bounds__(256, BF16 ? 4 : 2) void tower_kernel(const SepSeg* 
       }
     }
   } else {
-    // ---- headers: lane (r, g) owns column nt*16 + r of pixels (y0 + g, x0 + q), q = 0..3 ----
-    GLOBAL float* O = (GLOBAL float*)sg->out + (int64_t)b * sg->out_bstride + sg->out_off;
+    // ---- headers: lane (r, g) owns columns nt*16 + 4g .. +3 of pixel r: one (4-byte aligned) 16-byte
+    //      store per n-tile where the head's columns are contiguous in [B, N_anchors, K] ----
+    typedef float __attribute__((ext_vector_type(4), aligned(4))) f32x4_u;
     const int kin = sg->col_kin, kout = sg->col_kout, coff = sg->col_off, nbase = sg->n_base;
-    const int64_t rs = sg->out_rowstride;
-    const int ym = y0 + g;
-    const int64_t prow = ((int64_t)ym * w + x0) * rs;
+    GLOBAL float* O = (GLOBAL float*)sg->out + (int64_t)b * sg->out_bstride + sg->out_off + ((int64_t)y * w + x) * sg->out_rowstride;
+    const bool contiguous = kin == kout && coff == 0;
 #pragma unroll 2
     for (int nt = 0; nt < tilesN; nt++) {
-      const int n = nt * 16 + r;
-      const float bias = bias_s[n];
-      f32x4 acc = (f32x4){bias, bias, bias, bias};
+      const int n = nt * 16 + 4 * g;
+      f32x4 acc = *reinterpret_cast<const f32x4*>(bias_s + n);
 #pragma unroll(KU)
-      for (int ks = 0; ks < KS; ks++) acc = F::mma(xa_s[ks * 64], wfrag(n, ks), acc);
-      if (n < N && ym < h) {
-        const int nn = nbase + n;
-        const int col = (nn / kin) * kout + nn % kin + coff;
+      for (int ks = 0; ks < KS; ks++) acc = F::mma(wfrag(nt * 16 + r, ks), xa_s[ks * 64], acc);
+      if (pix_ok && n < N) {
         if (act == ACT_SIGMOID) {
 #pragma unroll
           for (int q = 0; q < 4; q++) acc[q] = sigmoid_t<BF16>(acc[q]);
@@ -300,9 +348,15 @@ __global__ __launch_bounds__(256, BF16 ? 4 : 2) void tower_kernel(const SepSeg* 
 #pragma unroll
           for (int q = 0; q < 4; q++) acc[q] = swish_t<BF16>(acc[q]);
         }
+        if (contiguous && n + 4 <= N) {
+          *(GLOBAL f32x4_u*)(O + nbase + n) = acc;
+        } else {
 #pragma unroll
-        for (int q = 0; q < 4; q++)
-          if (x0 + q < w) O[prow + q * rs + col] = acc[q];
+          for (int q = 0; q < 4; q++) {
+            const int nn = nbase + n + q;
+            if (n + q < N) O[(nn / kin) * kout + nn % kin + coff] = acc[q];
+          }
+        }
       }
     }
   }
