@@ -164,7 +164,7 @@ def main():
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         out = {
-            "metric": METRIC, "value": round(B * world * args.steps / elapsed, 2), "unit": "frames/s",
+            "metric": METRIC if (B, S, phi) == (16, 256, 0) else f"frames/sec at {S}x{S} bs{B} EfficientPose-phi{phi}; ADD(-S) vs ref", "value": round(B * world * args.steps / elapsed, 2), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic",
