@@ -12,4 +12,7 @@ def __getattr__(name):   # torch custom-op registration happens on first use of 
     if name in ("HMDEgoPose", "TrainModelWithLoss", "Session"):
         from . import model
         return getattr(model, name)
+    if name == "InflightPool":
+        from .pipeline import InflightPool
+        return InflightPool
     raise AttributeError(name)

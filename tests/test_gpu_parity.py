@@ -216,3 +216,33 @@ def test_alternative_plans_keep_parity(api, env, monkeypatch):
     for a, b in zip(out[0], ref[0]):
         assert (a.cpu() - b).abs().max().item() <= 1e-3
     s.close()
+
+
+def test_inflight_pool_matches_single_session():
+    """Four batches in flight on four streams give bit-identical results to one session run serially."""
+    import torch
+    from hmd_ego_pose_amd import InflightPool
+    from hmd_ego_pose_amd.model import Session
+    from hmd_ego_pose_amd.weights import seeded_state_dict
+    sd = seeded_state_dict(0, 0)
+    B, S = 4, 256
+    pool = InflightPool(sd, 0, S, B, "bf16", depth=3)
+    ref = Session(sd, 0, S, B, "bf16")
+    cam = torch.tensor([[480, 480, 128, 128, 1000, 1.0]] * B, device="cuda")
+    g = torch.Generator(device="cuda"); g.manual_seed(3)
+    batches = [torch.randn(B if i % 2 == 0 else B - 1, 3, S, S, device="cuda", generator=g) for i in range(7)]
+    got = []
+    for x in batches:
+        r = pool.submit(x, cam[:x.shape[0]])
+        if r is not None:
+            got.append({k: v.clone() for k, v in r.items()})
+    got += [{k: v.clone() for k, v in r.items()} for r in pool.drain()]
+    assert len(got) == len(batches)
+    for x, r in zip(batches, got):
+        _, reg, cls, rot, trn, hand = ref.forward(x, want_features=False)
+        boxes, trans = ref.decode(reg, trn, cam[:x.shape[0]])
+        torch.cuda.synchronize()
+        for k, t in (("regression", reg), ("classification", cls), ("rotation", rot), ("translation_raw", trn), ("hand", hand),
+                     ("boxes", boxes), ("translation", trans)):
+            assert r[k].shape == t.shape and torch.equal(r[k], t), k
+    pool.close(); ref.close()
