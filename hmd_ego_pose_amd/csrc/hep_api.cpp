@@ -41,6 +41,19 @@ Session::~Session() {
 }
 
 void launch_op(const Session& s, const Op& op, int batch, hipStream_t st, const float* in, const int64_t* strides) {
+  // HEP_SKIP_OPS=<substring>[,<substring>..]: leave out the launches whose name matches (removal experiments
+  // for timing only - the results are garbage)
+  static const char* skip = getenv("HEP_SKIP_OPS");
+  if (skip) {
+    std::string list(skip); size_t p0 = 0;
+    while (p0 <= list.size()) {
+      const size_t p1 = list.find(',', p0);
+      const std::string pat = list.substr(p0, p1 == std::string::npos ? std::string::npos : p1 - p0);
+      if (!pat.empty() && op.name.find(pat) != std::string::npos) return;
+      if (p1 == std::string::npos) break;
+      p0 = p1 + 1;
+    }
+  }
   switch (op.kind) {
     case OP_STEM: {
       StemArgs a = op.stem; a.B = batch; a.in = in;
