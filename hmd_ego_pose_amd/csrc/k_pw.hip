@@ -36,7 +36,9 @@ struct Step {
   typename Frag<BF16>::raw w[NT];   // weight fragments
 };
 
-template <bool BF16, int MT, int NT, int MODE>
+// ACT (none | swish) is a template parameter: with a run-time activation the epilogue carried a scalar
+// branch per output element
+template <bool BF16, int MT, int NT, int MODE, int ACT>
 __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
   typedef Vec8<BF16> V;
   typedef typename V::elem T;
@@ -168,7 +170,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
       if (!mok[i]) continue;
       float v[4];
 #pragma unroll
-      for (int q = 0; q < 4; q++) v[q] = apply_act_t<BF16>(acc[i][j][q] + b[q], a.act);
+      for (int q = 0; q < 4; q++) { const float x = acc[i][j][q] + b[q]; v[q] = ACT == ACT_SWISH ? swish_t<BF16>(x) : x; }
       const int64_t o = (int64_t)mrow[i] * a.N + n;
       if (R) {
         float rr[4]; V::load4(R, o, rr);
@@ -183,7 +185,8 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
 template <bool BF16, int MT, int MODE>
 static void launch_nt(const PwArgs& a, dim3 grid, hipStream_t s) {
   switch (a.NT) {
-#define CASE(n) case n: hipLaunchKernelGGL((pw_gemm_kernel<BF16, MT, n, MODE>), grid, dim3(256), 0, s, a); break;
+#define CASE(n) case n: if (a.act == ACT_SWISH) hipLaunchKernelGGL((pw_gemm_kernel<BF16, MT, n, MODE, ACT_SWISH>), grid, dim3(256), 0, s, a); \
+                else hipLaunchKernelGGL((pw_gemm_kernel<BF16, MT, n, MODE, ACT_NONE>), grid, dim3(256), 0, s, a); break;
     CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
 #undef CASE
   }
