@@ -446,7 +446,7 @@ int hep_kernel_symbol(const hep_handle* h, int i, const char** symbol) {
   char tmp[128];
   switch (o.kind) {
     case OP_STEM: snprintf(tmp, sizeof tmp, "stem_kernel<%s>", t); break;
-    case OP_PW: snprintf(tmp, sizeof tmp, "pw_gemm_kernel<%s, %d, %d, %d, %d>", t, o.pw.mode == 0 ? o.pw.MT : 1, o.pw.NT, o.pw.mode, o.pw.act == ACT_SWISH ? 1 : 0); break;
+    case OP_PW: snprintf(tmp, sizeof tmp, "pw_gemm_kernel<%s, %d, %d, %d, %d>", t, o.pw.MT, o.pw.NT, o.pw.mode, o.pw.act == ACT_SWISH ? 1 : 0); break;
     case OP_DW: snprintf(tmp, sizeof tmp, "dw_kernel<%s, %d, %d, %d>", t, o.dw.k, o.dw.s, o.dw.TW); break;
     case OP_SE: snprintf(tmp, sizeof tmp, "se_kernel"); break;
     case OP_POOL: snprintf(tmp, sizeof tmp, "pool_kernel<%s>", t); break;

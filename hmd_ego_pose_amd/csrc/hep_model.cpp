@@ -264,8 +264,13 @@ struct Planner {
       } else {                      // small maps, wide N (expand / lateral): waves side by side in N
         o.pw.mode = 1; o.pw.MT = 1; o.pw.NT = clampi(strips * tilesN / (4 * 256), 1, std::min(8, (tilesN + 3) / 4));
       }
-      // (measured and rejected on MI355X: two m-tiles per wave in modes 1/2 to halve the W re-reads from
-      //  L2, and a 3-deep fragment ring - neither moved these layers, they sit ~3 us above an empty launch)
+      // Two m-tiles per wave in modes 1/2 (every weight fragment feeds two MFMAs, half the weight re-reads
+      // from L2): no effect on a single batch in flight, but -2.5 % on the step with 4 batches in flight and
+      // at batch 64, where these layers are bound by L2 traffic and not by latency.  HEP_PW_MT2=0 disables.
+      {
+        const char* e = getenv("HEP_PW_MT2");
+        if (o.pw.mode != 0 && strips >= 8 && !(e && atoi(e) == 0)) { o.pw.MT = 2; o.pw.NT = std::min(o.pw.NT, 4); }
+      }
     }
     wref(op, F_PW_W, wb.put_typed(wf)); wref(op, F_PW_B, wb.put_f32(bf));
     tref(op, F_PW_A, in_t, false); tref(op, F_PW_OUT, out_t, true);

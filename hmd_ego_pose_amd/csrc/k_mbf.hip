@@ -29,6 +29,15 @@
 #define MBF_THREADS 512
 #define MBF_WAVES 8
 
+// Optional per-wave timeline (make EXTRA=-DHEP_MBF_TRACE): s_memrealtime (100 MHz) stamps at the phase
+// boundaries of the LAST mbf launch, read back with hep_dbg_mbf_trace() - profiling builds only.
+#ifdef HEP_MBF_TRACE
+__device__ unsigned long long* g_mbf_trace = nullptr;
+#define MSTAMP(i) do { stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define MSTAMP(i)
+#endif
+
 template <bool BF16, int KS, int S>
 __global__ __launch_bounds__(MBF_THREADS) void mbf_kernel(MbfArgs a) {
   typedef Vec8<BF16> V;
@@ -39,6 +48,10 @@ __global__ __launch_bounds__(MBF_THREADS) void mbf_kernel(MbfArgs a) {
   constexpr int PW = (TS - 1) * S + KS;              // input tile side
   constexpr int PIN = PW * PW;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#ifdef HEP_MBF_TRACE
+  unsigned long long stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  MSTAMP(0);
+#endif
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, g = lane >> 4;
   const int chunks = (a.Cexp + a.CC - 1) / a.CC;
@@ -117,7 +130,9 @@ __global__ __launch_bounds__(MBF_THREADS) void mbf_kernel(MbfArgs a) {
       }
     }
   }
+  MSTAMP(1);
   __syncthreads();
+  MSTAMP(2);
 
   // ---- phase B: expand 1x1 + bias + swish -> e_s ----
   if (a.has_expand) {
@@ -166,8 +181,10 @@ __global__ __launch_bounds__(MBF_THREADS) void mbf_kernel(MbfArgs a) {
         }
       }
     }
+    MSTAMP(3);
     __syncthreads();
   }
+  MSTAMP(4);
 
   // ---- phase C: depthwise taps from LDS -> global, SE sums ----
   // A lane owns TWO horizontally adjacent output pixels: their kx windows overlap, so a row of
@@ -217,6 +234,7 @@ __global__ __launch_bounds__(MBF_THREADS) void mbf_kernel(MbfArgs a) {
       }
     }
   }
+  MSTAMP(5);
   __syncthreads();      // a_s is dead: reuse as reduction scratch [MBF_THREADS][9]
 
   // ---- phase D: per-block channel sums, fixed order: butterfly over the lanes of a wave that share a
@@ -239,7 +257,27 @@ __global__ __launch_bounds__(MBF_THREADS) void mbf_kernel(MbfArgs a) {
       a.partial[((int64_t)b * tiles + tile) * a.Cexp + c0 + o] = s;
     }
   }
+#ifdef HEP_MBF_TRACE
+  MSTAMP(6);
+  if (g_mbf_trace && lane == 0) {
+    unsigned long long* o = g_mbf_trace + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * MBF_WAVES + wave) * 8;
+    for (int i = 0; i < 7; i++) o[i] = stamps[i];
+    o[7] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+  }
+#endif
 }
+
+#ifdef HEP_MBF_TRACE
+extern "C" int hep_dbg_mbf_trace(unsigned long long* host, int max_waves, int enable) {
+  static unsigned long long* buf = nullptr;
+  const size_t cap = (size_t)1 << 21;
+  if (!buf) { if (hipMalloc((void**)&buf, cap * 8) != hipSuccess) return -1; hipMemset(buf, 0, cap * 8); }
+  unsigned long long* p = enable ? buf : nullptr;
+  hipMemcpyToSymbol(HIP_SYMBOL(g_mbf_trace), &p, sizeof p);
+  if (host) { hipDeviceSynchronize(); hipMemcpy(host, buf, (size_t)max_waves * 64, hipMemcpyDeviceToHost); }
+  return (int)(cap / 8);
+}
+#endif
 
 size_t mbf_lds_layout(int Cin, int CC, int k, int s, int bf16, int has_expand, MbfArgs* a) {
   const size_t es = bf16 ? 2 : 4, pad = bf16 ? 8 : 4;

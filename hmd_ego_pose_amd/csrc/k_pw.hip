@@ -148,13 +148,17 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
   }
 
   if (MODE == 2) {   // meet the four K-slices in LDS; wave w finishes n-tiles j = w, w+4, ...
-    __shared__ f32x4 red[4][NT][64];
+    __shared__ f32x4 red[4][MT][NT][64];
 #pragma unroll
-    for (int j = 0; j < NT; j++) red[wave][j][lane] = acc[0][j];
+    for (int i = 0; i < MT; i++)
+#pragma unroll
+      for (int j = 0; j < NT; j++) red[wave][i][j][lane] = acc[i][j];
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < NT; j++)
-      if ((j & 3) == wave) acc[0][j] = (red[0][j][lane] + red[1][j][lane]) + (red[2][j][lane] + red[3][j][lane]);
+    for (int i = 0; i < MT; i++)
+#pragma unroll
+      for (int j = 0; j < NT; j++)
+        if ((j & 3) == wave) acc[i][j] = (red[0][i][j][lane] + red[1][i][j][lane]) + (red[2][i][j][lane] + red[3][i][j][lane]);
   }
 
   // ---- epilogue: lane holds n = nt*16 + 4g + {0..3} for pixel row m0 + 16 i + r ----
@@ -196,11 +200,11 @@ template <bool BF16>
 static void launch_t(const PwArgs& a, hipStream_t s) {
   const int per_block_n = a.mode == 1 ? 4 * a.NT : a.NT;
   const int chunksN = (a.tilesN + per_block_n - 1) / per_block_n;
-  const int rows = a.mode == 0 ? 64 * a.MT : 16;
+  const int rows = a.mode == 0 ? 64 * a.MT : 16 * a.MT;
   dim3 grid(((a.M + rows - 1) / rows) * chunksN);
   if (a.mode == 0) { if (a.MT == 2) launch_nt<BF16, 2, 0>(a, grid, s); else launch_nt<BF16, 1, 0>(a, grid, s); }
-  else if (a.mode == 1) launch_nt<BF16, 1, 1>(a, grid, s);
-  else launch_nt<BF16, 1, 2>(a, grid, s);
+  else if (a.mode == 1) { if (a.MT == 2) launch_nt<BF16, 2, 1>(a, grid, s); else launch_nt<BF16, 1, 1>(a, grid, s); }
+  else { if (a.MT == 2) launch_nt<BF16, 2, 2>(a, grid, s); else launch_nt<BF16, 1, 2>(a, grid, s); }
 }
 
 void launch_pw(const PwArgs& a, hipStream_t s) {
