@@ -304,12 +304,12 @@ struct Planner {
     // fused front (expand -> LDS -> depthwise, k_mbf.hip) whenever its LDS tiles fit; the expanded
     // tensor then never reaches HBM.  HEP_NO_MBF=1 forces the two-kernel path (A/B measurements).
     int CC = 0;
-    // Measured on MI355X at bs16 (profiles/README.md): the fused kernel beats expand+depthwise on
-    // the 32x32 and 16x16 input maps (-30 us per forward) and loses on the big early maps
-    // (bandwidth-bound, the two-kernel path already streams well) and on the 8x8 maps (too few
-    // workgroups per launch).  HEP_MBF=all|none overrides for A/B runs.
+    // Measured on MI355X at bs16 (profiles/README.md): the fused kernel beats expand+depthwise on input
+    // maps up to 32x32 (it expands only the tile pixels inside the image, so on the 8x8 maps the halo costs
+    // nothing) and loses on the big early maps (bandwidth-bound, the two-kernel path already streams well;
+    // stride-2 halos there cost up to 4.5x recompute).  HEP_MBF=all|none overrides for A/B runs.
     const char* mode = getenv("HEP_MBF");
-    const bool want = mode ? !strcmp(mode, "all") : (Hin == 16 || Hin == 32);
+    const bool want = mode ? !strcmp(mode, "all") : Hin <= 32;
     if (want && !(mode && !strcmp(mode, "none")))
       for (int cand : {64, 32, 16})
         if (mbf_lds_layout(b.cin, std::min(cand, b.expand ? cand : b.cexp), b.k, b.stride, s->dtype, b.expand, nullptr) <= 159 * 1024) { CC = cand; break; }

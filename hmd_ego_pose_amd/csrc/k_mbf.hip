@@ -12,8 +12,8 @@
 //   phase A  input tile (with halo, zero outside the image) -> LDS [PIN pixels][K]
 //   phase B  expand: D[n, pixel] = We[n,:] . tile[pixel,:] (the transposed MFMA product of
 //            k_pw.hip; weight fragments run 4 deep ahead in a register ring) -> +bias, swish ->
-//            LDS [PIN][CC]; pixels outside the image are written as ZERO (the depthwise pads the
-//            *activated* map, reference utils_extra.py:33-44)
+//            LDS [PIN][CC]; only the tile pixels inside the image are expanded, the others are the
+//            depthwise conv's padding of the *activated* map (reference utils_extra.py:33-44): zeros
 //   phase C  depthwise taps from LDS (weights in LDS) -> +bias, swish -> global, 16 bytes per lane;
 //            per-lane channel sums for squeeze-excite
 //   phase D  deterministic LDS reduction of the sums -> partial[b][tile][c]   (no atomics)
@@ -37,6 +37,9 @@ __device__ unsigned long long* g_mbf_trace = nullptr;
 #else
 #define MSTAMP(i)
 #endif
+
+// exact x / d for x * d < 2^32 with rcp = floor(2^32 / d) + 1
+__device__ __forceinline__ int fast_div_u(int x, uint32_t rcp) { return (int)__umulhi((uint32_t)x, rcp); }
 
 template <bool BF16, int KS, int S>
 __global__ __launch_bounds__(MBF_THREADS) void mbf_kernel(MbfArgs a) {
@@ -75,10 +78,11 @@ __global__ __launch_bounds__(MBF_THREADS) void mbf_kernel(MbfArgs a) {
   // ---- phase A: everything this workgroup needs, global -> LDS, all loads issued in batches of 8
   //      before the first LDS store (one memory round trip per batch): depthwise weights + biases,
   //      the expand-weight chunk [cc][K], and the input tile (zero outside the image) ----
-  constexpr int mtiles = (PIN + 15) / 16;
   const int ntiles = (cc + 15) / 16;
   const int ksteps = (K + KSTEP - 1) / KSTEP;
-  const int npairs = a.has_expand ? mtiles * ntiles : 0;           // pair = nt * mtiles + mt
+  const int r0 = max(0, -iy0), r1 = min(PW, a.H - iy0), q0 = max(0, -ix0), q1 = min(PW, a.W - ix0);   // inside rectangle
+  const int wi = q1 - q0, n_in = wi * (r1 - r0);
+  const uint32_t wi_rcp = (uint32_t)(0x100000000ull / (uint32_t)wi) + 1;   // uniform: one scalar division per workgroup
   // (index arithmetic: every divisor below is a compile-time constant or a power of two - a run-time
   //  integer division costs ~30 VALU instructions and this kernel used to spend most of its issue
   //  slots on them)
@@ -100,8 +104,15 @@ __global__ __launch_bounds__(MBF_THREADS) void mbf_kernel(MbfArgs a) {
     // rows = the expand-weight rows c0 .. c0 + 16*ntiles, then the PIN input pixels
     int vsh = 0; while ((1 << vsh) < vecs) vsh++;
     const int v = threadIdx.x & ((1 << vsh) - 1), row0 = threadIdx.x >> vsh, rstride = MBF_THREADS >> vsh;
-    const int n_wrows = a.has_expand ? ntiles * 16 : 0, n_rows = n_wrows + PIN;
+    // with an expand stage only the tile pixels INSIDE the image are staged (compact rows mc = ri * wi + ci
+    // of the rectangle [r0,r1) x [q0,q1) of the PW x PW tile) and expanded; the rest of the expanded tile is
+    // the zero padding of the depthwise conv and is written as zeros right here
+    const int n_wrows = a.has_expand ? ntiles * 16 : 0, n_rows = n_wrows + (a.has_expand ? n_in : PIN);
     const T* Wg = reinterpret_cast<const T*>(a.we) + (int64_t)c0 * K;
+    if (a.has_expand) {
+      const int nv = PIN * EP * (int)sizeof(T) / 16;               // the whole [PIN][EP] tile in 16-byte vectors
+      for (int i = threadIdx.x; i < nv; i += MBF_THREADS) reinterpret_cast<u32x4*>(e_s)[i] = (u32x4){0, 0, 0, 0};
+    }
     for (int base = 0; base < ((a.dbg_skip & 1) ? 0 : n_rows); base += rstride * NB) {
       raw_t x0[NB], x1[NB];
 #pragma unroll
@@ -112,7 +123,8 @@ __global__ __launch_bounds__(MBF_THREADS) void mbf_kernel(MbfArgs a) {
           const T* src = nullptr;
           if (row < n_wrows) src = Wg + (int64_t)row * K + v * 8;
           else {
-            const int p = row - n_wrows;
+            int p = row - n_wrows;
+            if (a.has_expand) { const int ri = fast_div_u(p, wi_rcp); p = (r0 + ri) * PW + q0 + (p - ri * wi); }
             const int gy = iy0 + p / PW, gx = ix0 + p % PW;
             if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) src = reinterpret_cast<const T*>(a.in) + img + ((int64_t)gy * a.W + gx) * K + cbase + v * 8;
           }
@@ -138,9 +150,11 @@ __global__ __launch_bounds__(MBF_THREADS) void mbf_kernel(MbfArgs a) {
   if (a.has_expand) {
     // a wave takes TWO m-tiles per weight fragment (one LDS weight read feeds two MFMAs) and keeps
     // three k-steps of fragments in flight
-    constexpr int mpairs = (mtiles + 1) / 2;
-    for (int pp = wave; pp < ((a.dbg_skip & 2) ? 0 : mpairs * ntiles); pp += MBF_WAVES) {
-      const int nt = pp / mpairs, mp = pp - nt * mpairs;           // mpairs is a compile-time constant
+    const int mpairs = (n_in + 31) >> 5;                           // pairs of 16-pixel m-tiles over the inside pixels
+    int ntsh = 0; while ((1 << ntsh) < ntiles) ntsh++;             // pp -> (mp, nt): a shift and a mask
+    for (int pp = wave; pp < ((a.dbg_skip & 2) ? 0 : mpairs << ntsh); pp += MBF_WAVES) {
+      const int nt = pp & ((1 << ntsh) - 1), mp = pp >> ntsh;
+      if (nt >= ntiles) continue;
       const int m0 = mp * 32 + r, m1 = m0 + 16;
       const T* wrow = w_s + (int64_t)(nt * 16 + r) * KP + KLANE * g;
       const T* arow0 = a_s + (int64_t)m0 * KP + KLANE * g;
@@ -152,8 +166,8 @@ __global__ __launch_bounds__(MBF_THREADS) void mbf_kernel(MbfArgs a) {
         raw_t wf = {}, xa0 = {}, xa1 = {};
         if (k < K) {
           wf = *reinterpret_cast<const raw_t*>(wrow + ks * KSTEP);
-          if (m0 < PIN) xa0 = *reinterpret_cast<const raw_t*>(arow0 + ks * KSTEP);
-          if (m1 < PIN) xa1 = *reinterpret_cast<const raw_t*>(arow1 + ks * KSTEP);
+          if (m0 < n_in) xa0 = *reinterpret_cast<const raw_t*>(arow0 + ks * KSTEP);
+          if (m1 < n_in) xa1 = *reinterpret_cast<const raw_t*>(arow1 + ks * KSTEP);
         }
         if constexpr (BF16) {
           acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf), __builtin_bit_cast(bf16x8, xa0), acc0, 0, 0, 0);
@@ -169,14 +183,13 @@ __global__ __launch_bounds__(MBF_THREADS) void mbf_kernel(MbfArgs a) {
 #pragma unroll
         for (int half = 0; half < 2; half++) {
           const int m = half ? m1 : m0;
-          if (m < PIN) {
+          if (m < n_in) {
             const f32x4 acc = half ? acc1 : acc0;
-            const int gy = iy0 + m / PW, gx = ix0 + m % PW;
-            const bool inside = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            const int ri = fast_div_u(m, wi_rcp), p = (r0 + ri) * PW + q0 + (m - ri * wi);   // tile position of inside pixel m
             float v[4];
 #pragma unroll
-            for (int q = 0; q < 4; q++) v[q] = inside ? swish_t<BF16>(acc[q] + bias[q]) : 0.f;
-            V::store4(e_s, (int64_t)m * EP + n, v);
+            for (int q = 0; q < 4; q++) v[q] = swish_t<BF16>(acc[q] + bias[q]);
+            V::store4(e_s, (int64_t)p * EP + n, v);
           }
         }
       }
