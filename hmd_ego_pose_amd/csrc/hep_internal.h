@@ -140,6 +140,7 @@ void launch_dw(const DwArgs&, hipStream_t);
 void launch_se(const SeArgs&, hipStream_t);
 void launch_pool(const PoolArgs&, hipStream_t);
 void launch_mbf(const MbfArgs&, hipStream_t);
+#define MBF_SUM_ROWS 4            // waves of an mbf workgroup that run the depthwise phase (CC <= 64): partial-sum rows per tile
 size_t mbf_lds_layout(int Cin, int CC, int k, int s, int bf16, int has_expand, MbfArgs* a);
 int mbf_prepare(void);
 void launch_sep(const SepArgs&, hipStream_t);

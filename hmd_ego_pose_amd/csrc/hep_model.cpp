@@ -316,7 +316,7 @@ struct Planner {
     int part_t, nblk;
     if (CC) {
       if (!b.expand) CC = std::min(CC, b.cexp);
-      nblk = ((Ho + 7) / 8) * ((Wo + 7) / 8);
+      nblk = ((Ho + 7) / 8) * ((Wo + 7) / 8) * MBF_SUM_ROWS;
       snprintf(nm, sizeof nm, "b%d.se_partial", i);
       part_t = tensor(nm, 1, nblk, b.cexp, true);
       snprintf(nm, sizeof nm, "b%d.front", i);
@@ -356,7 +356,7 @@ struct Planner {
       const bool lds_dw = dl ? atoi(dl) != 0 : (Hin <= 8 || (b.k == 5 && Hin <= 64));
       const int ccl = std::min(64, b.cexp);
       if (lds_dw && mbf_lds_layout(b.cexp, ccl, b.k, b.stride, s->dtype, 0, nullptr) <= 159 * 1024) {
-        nblk = ((Ho + 7) / 8) * ((Wo + 7) / 8);
+        nblk = ((Ho + 7) / 8) * ((Wo + 7) / 8) * MBF_SUM_ROWS;
         snprintf(nm, sizeof nm, "b%d.se_partial", i);
         part_t = tensor(nm, 1, nblk, b.cexp, true);
         snprintf(nm, sizeof nm, "b%d.dw", i);

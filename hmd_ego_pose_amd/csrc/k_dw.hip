@@ -230,19 +230,33 @@ void launch_dw(const DwArgs& a_, hipStream_t s) {
 #define SE_THREADS 1024
 #define SE_SPLIT 4
 __global__ __launch_bounds__(SE_THREADS) void se_kernel(SeArgs a) {
-  extern __shared__ float sm[];          // mean[C] | hidden[sq]
+  extern __shared__ float sm[];          // mean[C] | hidden[sq] | slice sums [S][C]
   float* mean = sm;
   float* hid = sm + a.C;
   const int b = blockIdx.x;
-  for (int c = threadIdx.x; c < a.C; c += SE_THREADS) {
-    const float* p = a.partial + (int64_t)b * a.nblk * a.C + c;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int i = 0;
-    for (; i + 4 <= a.nblk; i += 4) {
-      s0 += p[(int64_t)i * a.C]; s1 += p[(int64_t)(i + 1) * a.C]; s2 += p[(int64_t)(i + 2) * a.C]; s3 += p[(int64_t)(i + 3) * a.C];
+  // mean: thread -> (slice, channel), t = sl * C + c; slice sl adds partial rows sl, sl + S, .. (fixed order),
+  // then the S slices of a channel are added up - all 1024 lanes load instead of C of them
+  {
+    const int C = a.C;
+    int S = SE_THREADS / C; if (S < 1) S = 1; if (S > a.nblk) S = a.nblk;
+    float* psum = hid + ((a.sq + 3) & ~3);
+    for (int t = threadIdx.x; t < S * C; t += SE_THREADS) {
+      const int sl = t / C, c = t - sl * C;
+      const float* p = a.partial + (int64_t)b * a.nblk * C + c;
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+      int i = sl;
+      for (; i + 3 * S < a.nblk; i += 4 * S) {
+        s0 += p[(int64_t)i * C]; s1 += p[(int64_t)(i + S) * C]; s2 += p[(int64_t)(i + 2 * S) * C]; s3 += p[(int64_t)(i + 3 * S) * C];
+      }
+      for (; i < a.nblk; i += S) s0 += p[(int64_t)i * C];
+      psum[t] = (s0 + s1) + (s2 + s3);
     }
-    for (; i < a.nblk; i++) s0 += p[(int64_t)i * a.C];
-    mean[c] = ((s0 + s1) + (s2 + s3)) * a.inv_hw;
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += SE_THREADS) {
+      float m = 0.f;
+      for (int sl = 0; sl < S; sl++) m += psum[sl * C + c];
+      mean[c] = m * a.inv_hw;
+    }
   }
   __syncthreads();
   // reduce FC: wave w owns rows w, w+16, w+32 (sq <= 48 on every EfficientNet up to B7: rows beyond
@@ -290,7 +304,9 @@ __global__ __launch_bounds__(SE_THREADS) void se_kernel(SeArgs a) {
   }
 }
 void launch_se(const SeArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(se_kernel, dim3(a.B, SE_SPLIT), dim3(SE_THREADS), (a.C + a.sq) * sizeof(float), s, a);
+  int S = SE_THREADS / a.C; if (S < 1) S = 1; if (S > a.nblk) S = a.nblk;
+  const size_t lds = ((size_t)a.C + ((a.sq + 3) & ~3) + (size_t)S * a.C) * sizeof(float);      // mean | hidden | slice sums
+  hipLaunchKernelGGL(se_kernel, dim3(a.B, SE_SPLIT), dim3(SE_THREADS), lds, s, a);
 }
 
 // ------------------------------------------------------------------------------------------------

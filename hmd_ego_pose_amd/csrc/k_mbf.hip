@@ -16,7 +16,7 @@
 //            depthwise conv's padding of the *activated* map (reference utils_extra.py:33-44): zeros
 //   phase C  depthwise taps from LDS (weights in LDS) -> +bias, swish -> global, 16 bytes per lane;
 //            per-lane channel sums for squeeze-excite
-//   phase D  deterministic LDS reduction of the sums -> partial[b][tile][c]   (no atomics)
+//   phase D  per-wave channel sums (wave butterfly, fixed order) -> partial[b][tile*4 + wave][c]   (no atomics)
 // Blocks without an expand conv (first block of the net) skip phase B: the input tile IS the
 // depthwise input.
 #include <stdlib.h>
@@ -73,7 +73,6 @@ __global__ __launch_bounds__(MBF_THREADS) void mbf_kernel(MbfArgs a) {
   float* wdw_s = reinterpret_cast<float*>(smem + a.off_w);         // [KS*KS][CC]
   float* be_s = wdw_s + KS * KS * a.CC;                            // [CC] expand bias
   float* bdw_s = be_s + a.CC;                                      // [CC] depthwise bias
-  float* red = reinterpret_cast<float*>(smem);                     // phase D scratch over the dead input tile
 
   // ---- phase A: everything this workgroup needs, global -> LDS, all loads issued in batches of 8
   //      before the first LDS store (one memory round trip per batch): depthwise weights + biases,
@@ -86,12 +85,31 @@ __global__ __launch_bounds__(MBF_THREADS) void mbf_kernel(MbfArgs a) {
   // (index arithmetic: every divisor below is a compile-time constant or a power of two - a run-time
   //  integer division costs ~30 VALU instructions and this kernel used to spend most of its issue
   //  slots on them)
-  int ccsh = 3; while ((1 << ccsh) < cc) ccsh++;
-  for (int i = threadIdx.x; i < (KS * KS) << ccsh; i += MBF_THREADS) {
-    const int tap = i >> ccsh, c = i & ((1 << ccsh) - 1);
-    if (c < cc) wdw_s[tap * a.CC + c] = a.wdw[(int64_t)tap * a.Cexp + c0 + c];
+  // depthwise weights + biases: 16-byte vectors, all loads of a thread issued before its first LDS store
+  // (one memory round trip; cc and c0 are multiples of 8)
+  {
+    constexpr int NDW = (KS * KS * 128 / 4 + MBF_THREADS - 1) / MBF_THREADS;     // CC <= 128
+    const int cv = cc >> 2;                                                      // float4 vectors per tap
+    int cvsh = 1; while ((1 << cvsh) < cv) cvsh++;
+    f32x4 wv[NDW];
+#pragma unroll
+    for (int j = 0; j < NDW; j++) {
+      const int i = threadIdx.x + j * MBF_THREADS, tap = i >> cvsh, c4 = i & ((1 << cvsh) - 1);
+      wv[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (tap < KS * KS && c4 < cv) wv[j] = *reinterpret_cast<const f32x4*>(a.wdw + (int64_t)tap * a.Cexp + c0 + c4 * 4);
+    }
+    f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int bi = threadIdx.x;                      // threads [0, cv): depthwise bias, [64, 64 + cv): expand bias
+    if (bi < cv) bv = *reinterpret_cast<const f32x4*>(a.bdw + c0 + bi * 4);
+    else if (a.has_expand && bi >= 64 && bi - 64 < cv) bv = *reinterpret_cast<const f32x4*>(a.be + c0 + (bi - 64) * 4);
+#pragma unroll
+    for (int j = 0; j < NDW; j++) {
+      const int i = threadIdx.x + j * MBF_THREADS, tap = i >> cvsh, c4 = i & ((1 << cvsh) - 1);
+      if (tap < KS * KS && c4 < cv) *reinterpret_cast<f32x4*>(wdw_s + tap * a.CC + c4 * 4) = wv[j];
+    }
+    if (bi < cv) *reinterpret_cast<f32x4*>(bdw_s + bi * 4) = bv;
+    else if (bi >= 64 && bi - 64 < cv) *reinterpret_cast<f32x4*>(be_s + (bi - 64) * 4) = bv;
   }
-  for (int c = threadIdx.x; c < cc; c += MBF_THREADS) { be_s[c] = a.has_expand ? a.be[c0 + c] : 0.f; bdw_s[c] = a.bdw[c0 + c]; }
   {
     constexpr int NB = BF16 ? 8 : 4;                               // 16-byte vectors (bf16) / 32-byte pairs (fp32) in flight per lane
     const int kv = K >> 3;                                         // 8-channel vectors per input pixel / weight row
@@ -248,26 +266,20 @@ __global__ __launch_bounds__(MBF_THREADS) void mbf_kernel(MbfArgs a) {
     }
   }
   MSTAMP(5);
-  __syncthreads();      // a_s is dead: reuse as reduction scratch [MBF_THREADS][9]
 
-  // ---- phase D: per-block channel sums, fixed order: butterfly over the lanes of a wave that share a
-  //      channel group (lane = cg mod cgp), then one LDS row per wave and a sum over the 8 waves ----
-  if (a.partial && !(a.dbg_skip & 8)) {
+  // ---- phase D: channel sums for the squeeze-excite mean, fixed order, no barrier: butterfly over the
+  //      lanes of a wave that share a channel group (lane = cg mod cgp), then lane cg of each of the
+  //      MBF_SUM_ROWS waves that ran phase C writes its row partial[b][tile * MBF_SUM_ROWS + wave][c]
+  //      (se_kernel adds the rows up) ----
+  if (a.partial && !(a.dbg_skip & 8) && wave < MBF_SUM_ROWS) {
     for (int off = cgp; off < 64; off <<= 1) {
 #pragma unroll
       for (int c = 0; c < 8; c++) sum[c] += __shfl_xor(sum[c], off, 64);
     }
-    if (lane < cgs) {            // cgp <= 16 (at most 128 channels per workgroup): lane cg of every wave holds its total
-      f32x4* d = reinterpret_cast<f32x4*>(red + (wave * cgp + lane) * 8);
+    if (lane < cgs) {
+      const int tiles = tiles_x * ((a.Ho + TS - 1) / TS);
+      f32x4* d = reinterpret_cast<f32x4*>(a.partial + (((int64_t)b * tiles + tile) * MBF_SUM_ROWS + wave) * a.Cexp + c0 + lane * 8);
       d[0] = (f32x4){sum[0], sum[1], sum[2], sum[3]}; d[1] = (f32x4){sum[4], sum[5], sum[6], sum[7]};
-    }
-    __syncthreads();
-    const int tiles = tiles_x * ((a.Ho + TS - 1) / TS);
-    for (int o = threadIdx.x; o < cc; o += MBF_THREADS) {
-      float s = 0.f;
-#pragma unroll
-      for (int w8 = 0; w8 < MBF_WAVES; w8++) s += red[(w8 * cgp + (o >> 3)) * 8 + (o & 7)];
-      a.partial[((int64_t)b * tiles + tile) * a.Cexp + c0 + o] = s;
     }
   }
 #ifdef HEP_MBF_TRACE
