@@ -220,25 +220,31 @@ __global__ __launch_bounds__(MBF_THREADS) void mbf_kernel(MbfArgs a) {
   // ---- phase C: depthwise taps from LDS -> global, SE sums ----
   // A lane owns TWO horizontally adjacent output pixels: their kx windows overlap, so a row of
   // S + KS input pixels is read (and unpacked) once for both and every weight vector read from LDS
-  // feeds two pixels - this phase is LDS-bandwidth-bound.
+  // feeds two pixels.  The 256 (pixel pair, channel group) items are split over BOTH halves of the
+  // workgroup by tap row: waves 0-3 take the first (KS+1)/2 rows of taps, waves 4-7 the rest and hand
+  // their partial sums over through LDS (the dead input tile) - the phase is a chain of dependent LDS
+  // reads per tap row, so halving the rows per lane shortens it.
   const int cgs = cc >> 3;
   int cgsh = 0; while ((1 << cgsh) < cgs) cgsh++;
   const int cgp = 1 << cgsh;
-  const int cg = threadIdx.x & (cgp - 1), pp = threadIdx.x >> cgsh;      // pixel pair 0 .. TS*TS/2 - 1
+  const int half = threadIdx.x >> 8, tl = threadIdx.x & 255;
+  const int cg = tl & (cgp - 1), pp = tl >> cgsh;                          // pixel pair 0 .. TS*TS/2 - 1
+  f32x4* xch = reinterpret_cast<f32x4*>(smem);                             // [4][256] float4: partial sums of waves 4-7
   float sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (cg < cgs && pp < TS * TS / 2 && !(a.dbg_skip & 4)) {
-    constexpr int NX = S + KS;
-    const int py = pp / (TS / 2), px = (pp % (TS / 2)) * 2;
-    const int oy = oy0 + py, ox = ox0 + px;
-    float acc0[8], acc1[8];
+  const bool item = cg < cgs && pp < TS * TS / 2 && !(a.dbg_skip & 4);
+  constexpr int KH = (KS + 1) / 2;
+  float acc0[8], acc1[8];
+  constexpr int NX = S + KS;
+  const int py = pp / (TS / 2), px = (pp % (TS / 2)) * 2;
+  if (item) {
     {
       const f32x4* bp = reinterpret_cast<const f32x4*>(bdw_s + cg * 8);
       const f32x4 b0 = bp[0], b1 = bp[1];
 #pragma unroll
-      for (int c = 0; c < 4; c++) { acc0[c] = b0[c]; acc0[4 + c] = b1[c]; acc1[c] = b0[c]; acc1[4 + c] = b1[c]; }
+      for (int c = 0; c < 4; c++) { acc0[c] = half ? 0.f : b0[c]; acc0[4 + c] = half ? 0.f : b1[c]; acc1[c] = acc0[c]; acc1[4 + c] = acc0[4 + c]; }
     }
 #pragma unroll 1      // a real loop: unrolled, the compiler hoists all KS*KS weight reads and spills
-    for (int ky = 0; ky < KS; ky++) {
+    for (int ky = half ? KH : 0; ky < (half ? KS : KH); ky++) {
       float ev[NX][8];
 #pragma unroll
       for (int j = 0; j < NX; j++) V::load(e_s, (int64_t)((py * S + ky) * PW + px * S + j) * EP + cg * 8, ev[j]);
@@ -253,6 +259,17 @@ __global__ __launch_bounds__(MBF_THREADS) void mbf_kernel(MbfArgs a) {
         }
       }
     }
+    if (half) {
+      xch[0 * 256 + tl] = (f32x4){acc0[0], acc0[1], acc0[2], acc0[3]}; xch[1 * 256 + tl] = (f32x4){acc0[4], acc0[5], acc0[6], acc0[7]};
+      xch[2 * 256 + tl] = (f32x4){acc1[0], acc1[1], acc1[2], acc1[3]}; xch[3 * 256 + tl] = (f32x4){acc1[4], acc1[5], acc1[6], acc1[7]};
+    }
+  }
+  __syncthreads();
+  if (item && !half) {
+    const f32x4 p0 = xch[tl], p1 = xch[256 + tl], p2 = xch[512 + tl], p3 = xch[768 + tl];
+#pragma unroll
+    for (int c = 0; c < 4; c++) { acc0[c] += p0[c]; acc0[4 + c] += p1[c]; acc1[c] += p2[c]; acc1[4 + c] += p3[c]; }
+    const int oy = oy0 + py, ox = ox0 + px;
     if (oy < a.Ho && ox < a.Wo) {
       float v[8];
 #pragma unroll
