@@ -64,6 +64,7 @@ void launch_op(const Session& s, const Op& op, int batch, hipStream_t st, const 
     case OP_DW: { DwArgs a = op.dw; a.B = batch; launch_dw(a, st); break; }
     case OP_SE: { SeArgs a = op.se; a.B = batch; launch_se(a, st); break; }
     case OP_POOL: { PoolArgs a = op.pool; a.B = batch; launch_pool(a, st); break; }
+    case OP_PWG: { PwgArgs a = op.pwg; a.B = batch; launch_pwg(a, st); break; }
     case OP_MBF: { MbfArgs a = op.mbf; a.B = batch; launch_mbf(a, st); break; }
     case OP_HEAD: { HeadArgs a = op.head; a.B = batch; launch_head(a, st); break; }
     case OP_SEP: {
@@ -450,6 +451,7 @@ int hep_kernel_symbol(const hep_handle* h, int i, const char** symbol) {
     case OP_DW: snprintf(tmp, sizeof tmp, "dw_kernel<%s, %d, %d, %d>", t, o.dw.k, o.dw.s, o.dw.TW); break;
     case OP_SE: snprintf(tmp, sizeof tmp, "se_kernel"); break;
     case OP_POOL: snprintf(tmp, sizeof tmp, "pool_kernel<%s>", t); break;
+    case OP_PWG: snprintf(tmp, sizeof tmp, "pw_group_kernel<%s>", t); break;
     case OP_MBF: snprintf(tmp, sizeof tmp, "mbf_kernel<%s, %d, %d>", t, o.mbf.k, o.mbf.s); break;
     case OP_HEAD: snprintf(tmp, sizeof tmp, "head_kernel<%s>", t); break;
     default: if (o.sep.direct) snprintf(tmp, sizeof tmp, "tower_kernel<%s, %d, %s>", t, o.sep.C, o.sep.direct == 2 ? "true" : "false");

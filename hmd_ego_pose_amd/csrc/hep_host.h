@@ -45,10 +45,10 @@ struct TensorDesc {
   void* ext_ptr = nullptr;
 };
 
-enum OpKind { OP_STEM, OP_PW, OP_DW, OP_SE, OP_POOL, OP_SEP, OP_MBF, OP_HEAD };
+enum OpKind { OP_STEM, OP_PW, OP_DW, OP_SE, OP_POOL, OP_SEP, OP_MBF, OP_HEAD, OP_PWG };
 struct Op {
   OpKind kind; std::string name;
-  StemArgs stem; PwArgs pw; DwArgs dw; SeArgs se; PoolArgs pool; SepArgs sep; MbfArgs mbf; HeadArgs head;
+  StemArgs stem; PwArgs pw; DwArgs dw; SeArgs se; PoolArgs pool; SepArgs sep; MbfArgs mbf; HeadArgs head; PwgArgs pwg;
   std::vector<SepSeg> segs;         // host copy (device copy uploaded at build)
   std::vector<HeadSeg> hsegs;
   std::vector<int> reads, writes;   // tensor ids

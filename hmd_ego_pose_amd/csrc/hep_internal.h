@@ -32,6 +32,11 @@ struct PwArgs {
   int mode;            // wave arrangement inside a workgroup: 0 along M, 1 along N, 2 split-K (k_pw.hip)
 };
 
+// ---- several small independent pointwise convs in ONE launch (the BiFPN lateral 1x1 convs) ----
+#define PWG_MAX 8
+struct PwgSeg { const void* A; const void* W; const float* bias; void* out; int HW, K, N, tilesN, blk_begin; };   // blk_begin: prefix of 16-row strips per image
+struct PwgArgs { PwgSeg seg[PWG_MAX]; int nseg, B, bf16, strips_per_image; };
+
 // ---- depthwise kxk conv + folded BN + swish (+ per-block channel sums for SE) ----
 struct DwArgs {
   const void* in; const float* w /*[k*k][C]*/; const float* bias; void* out;
@@ -136,6 +141,7 @@ struct FilterArgs {
 
 void launch_stem(const StemArgs&, hipStream_t);
 void launch_pw(const PwArgs&, hipStream_t);
+void launch_pwg(const PwgArgs&, hipStream_t);
 void launch_dw(const DwArgs&, hipStream_t);
 void launch_se(const SeArgs&, hipStream_t);
 void launch_pool(const PoolArgs&, hipStream_t);

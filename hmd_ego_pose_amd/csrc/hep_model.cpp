@@ -193,7 +193,7 @@ static bool fold_bn(const Pack& pk, const std::string& p, int c, BnFold* out, st
 // index after the plan is complete: each Op records symbolic references here.
 struct Ref { int op; int field; int seg; int idx; size_t woff; int tensor; };
 enum { F_STEM_W, F_STEM_B, F_STEM_OUT, F_PW_A, F_PW_W, F_PW_B, F_PW_SE, F_PW_RES, F_PW_OUT, F_DW_IN, F_DW_W, F_DW_B,
-       F_DW_OUT, F_DW_PART, F_MBF_IN, F_MBF_WE, F_MBF_BE, F_MBF_WDW, F_MBF_BDW, F_MBF_OUT, F_MBF_PART, F_SE_PART, F_SE_WR, F_SE_BR, F_SE_WE, F_SE_BE, F_SE_SCALE, F_POOL_IN, F_POOL_OUT,
+       F_DW_OUT, F_DW_PART, F_MBF_IN, F_MBF_WE, F_MBF_BE, F_MBF_WDW, F_MBF_BDW, F_MBF_OUT, F_MBF_PART, F_SE_PART, F_SE_WR, F_SE_BR, F_SE_WE, F_SE_BE, F_SE_SCALE, F_POOL_IN, F_POOL_OUT, F_PWG_A, F_PWG_W, F_PWG_B, F_PWG_OUT,
        F_SEG_SRC, F_SEG_WDW, F_SEG_WPW, F_SEG_BIAS, F_SEG_OUT,
        F_HSEG_FEAT, F_HSEG_WDW, F_HSEG_WPW, F_HSEG_BIAS, F_HOUT_WDW, F_HOUT_WPW, F_HOUT_BIAS, F_HOUT_OUT };
 
@@ -222,7 +222,7 @@ struct Planner {
   }
   int new_op(OpKind k, const std::string& name) {
     Op o; memset(&o.stem, 0, sizeof o.stem); memset(&o.pw, 0, sizeof o.pw); memset(&o.dw, 0, sizeof o.dw);
-    memset(&o.se, 0, sizeof o.se); memset(&o.pool, 0, sizeof o.pool); memset(&o.sep, 0, sizeof o.sep); memset(&o.mbf, 0, sizeof o.mbf); memset(&o.head, 0, sizeof o.head);
+    memset(&o.se, 0, sizeof o.se); memset(&o.pool, 0, sizeof o.pool); memset(&o.sep, 0, sizeof o.sep); memset(&o.mbf, 0, sizeof o.mbf); memset(&o.head, 0, sizeof o.head); memset(&o.pwg, 0, sizeof o.pwg);
     o.kind = k; o.name = name;
     s->ops.push_back(o);
     return (int)s->ops.size() - 1;
@@ -280,6 +280,42 @@ struct Planner {
     o.weight_bytes = (double)N * K * es();
     o.flops_per_image = 2.0 * HW * K * N;
     return out_t;
+  }
+
+  // ---- several independent pointwise convs (conv bias + BN folded, no activation) as ONE launch ----
+  struct PwSpec { std::string name, wkey, bkey, bnkey, out_name; int in_t, HW, K, H, W; };
+  std::vector<int> add_pw_group(const std::string& name, const std::vector<PwSpec>& specs, int N) {
+    std::vector<int> outs;
+    const int op = new_op(OP_PWG, name);
+    int strips = 0;
+    double bytes = 0, wbytes = 0, flops = 0;
+    for (size_t i = 0; i < specs.size(); i++) {
+      const PwSpec& sp = specs[i];
+      const PackTensor* w = get(sp.wkey, {N, sp.K, 1, 1});
+      const PackTensor* cb = sp.bkey.empty() ? nullptr : get(sp.bkey, {N});
+      BnFold bn;
+      if (!sp.bnkey.empty() && !fold_bn(pk, sp.bnkey, N, &bn, err)) ok = false;
+      if (!ok) return outs;
+      const int tilesN = (N + 15) / 16;
+      std::vector<float> wf((size_t)tilesN * 16 * sp.K, 0.f), bf((size_t)tilesN * 16, 0.f);
+      for (int n = 0; n < N; n++) {
+        const float sc = sp.bnkey.empty() ? 1.f : bn.scale[n], sh = sp.bnkey.empty() ? 0.f : bn.shift[n];
+        for (int k = 0; k < sp.K; k++) wf[(size_t)n * sp.K + k] = w->data[(size_t)n * sp.K + k] * sc;
+        bf[n] = (cb ? cb->data[n] : 0.f) * sc + sh;
+      }
+      const int out_t = tensor(sp.out_name, sp.H, sp.W, N);
+      outs.push_back(out_t);
+      PwgSeg& g = s->ops[op].pwg.seg[i];
+      g.HW = sp.HW; g.K = sp.K; g.N = N; g.tilesN = tilesN; g.blk_begin = strips;
+      strips += (sp.HW + 15) / 16;
+      wref(op, F_PWG_W, wb.put_typed(wf), (int)i); wref(op, F_PWG_B, wb.put_f32(bf), (int)i);
+      tref(op, F_PWG_A, sp.in_t, false, (int)i); tref(op, F_PWG_OUT, out_t, true, (int)i);
+      bytes += ((double)sp.HW * sp.K + (double)sp.HW * N) * es(); wbytes += (double)N * sp.K * es(); flops += 2.0 * sp.HW * sp.K * N;
+    }
+    Op& o = s->ops[op];
+    o.pwg.nseg = (int)specs.size(); o.pwg.bf16 = s->dtype; o.pwg.strips_per_image = strips;
+    o.act_bytes_per_image = bytes; o.weight_bytes = wbytes; o.flops_per_image = flops;
+    return outs;
   }
 
   // ---- MBConv block ----
@@ -580,18 +616,28 @@ int build_session(Session* s, const Pack& pack, std::string* err) {
     int in[5], in2[5];
     if (r == 0) {
       const int L3 = s->levels[0], L4 = s->levels[1], L5 = s->levels[2];
-      in[0] = P.add_pw(tn + "p3_down", taps[0], L3 * L3, A.tap_channels[0], Wf, p + ".p3_down_channel.0.conv.weight",
-                       p + ".p3_down_channel.0.conv.bias", p + ".p3_down_channel.1", ACT_NONE, -1, -1, tn + "p3_in", L3, L3);
-      in[1] = P.add_pw(tn + "p4_down", taps[1], L4 * L4, A.tap_channels[1], Wf, p + ".p4_down_channel.0.conv.weight",
-                       p + ".p4_down_channel.0.conv.bias", p + ".p4_down_channel.1", ACT_NONE, -1, -1, tn + "p4_in", L4, L4);
-      in[2] = P.add_pw(tn + "p5_down", taps[2], L5 * L5, A.tap_channels[2], Wf, p + ".p5_down_channel.0.conv.weight",
-                       p + ".p5_down_channel.0.conv.bias", p + ".p5_down_channel.1", ACT_NONE, -1, -1, tn + "p5_in", L5, L5);
-      in2[1] = P.add_pw(tn + "p4_down2", taps[1], L4 * L4, A.tap_channels[1], Wf, p + ".p4_down_channel_2.0.conv.weight",
-                        p + ".p4_down_channel_2.0.conv.bias", p + ".p4_down_channel_2.1", ACT_NONE, -1, -1, tn + "p4_in2", L4, L4);
-      in2[2] = P.add_pw(tn + "p5_down2", taps[2], L5 * L5, A.tap_channels[2], Wf, p + ".p5_down_channel_2.0.conv.weight",
-                        p + ".p5_down_channel_2.0.conv.bias", p + ".p5_down_channel_2.1", ACT_NONE, -1, -1, tn + "p5_in2", L5, L5);
-      const int p6pre = P.add_pw(tn + "p5_to_p6", taps[2], L5 * L5, A.tap_channels[2], Wf, p + ".p5_to_p6.0.conv.weight",
-                                 p + ".p5_to_p6.0.conv.bias", p + ".p5_to_p6.1", ACT_NONE, -1, -1, tn + "p6_pre", L5, L5);
+      // the six lateral 1x1 convs only depend on the backbone taps: one grouped launch (HEP_PWG=0: six launches)
+      int p6pre;
+      struct Lat { const char* nm; int tap, L; const char* key; const char* out; };
+      const Lat lat[6] = {{"p3_down", 0, L3, ".p3_down_channel", "p3_in"}, {"p4_down", 1, L4, ".p4_down_channel", "p4_in"},
+                          {"p5_down", 2, L5, ".p5_down_channel", "p5_in"}, {"p4_down2", 1, L4, ".p4_down_channel_2", "p4_in2"},
+                          {"p5_down2", 2, L5, ".p5_down_channel_2", "p5_in2"}, {"p5_to_p6", 2, L5, ".p5_to_p6", "p6_pre"}};
+      int lat_out[6];
+      const char* ge = getenv("HEP_PWG");
+      if (!(ge && atoi(ge) == 0)) {
+        std::vector<Planner::PwSpec> specs;
+        for (const Lat& l : lat)
+          specs.push_back({tn + l.nm, p + l.key + ".0.conv.weight", p + l.key + ".0.conv.bias", p + l.key + ".1", tn + l.out,
+                           taps[l.tap], l.L * l.L, A.tap_channels[l.tap], l.L, l.L});
+        const std::vector<int> outs = P.add_pw_group(tn + "laterals", specs, Wf);
+        if (!P.ok || outs.size() != 6) return HEP_ERR_PACK;
+        for (int i = 0; i < 6; i++) lat_out[i] = outs[i];
+      } else {
+        for (int i = 0; i < 6; i++)
+          lat_out[i] = P.add_pw(tn + lat[i].nm, taps[lat[i].tap], lat[i].L * lat[i].L, A.tap_channels[lat[i].tap], Wf, p + lat[i].key + ".0.conv.weight",
+                                p + lat[i].key + ".0.conv.bias", p + lat[i].key + ".1", ACT_NONE, -1, -1, tn + lat[i].out, lat[i].L, lat[i].L);
+      }
+      in[0] = lat_out[0]; in[1] = lat_out[1]; in[2] = lat_out[2]; in2[1] = lat_out[3]; in2[2] = lat_out[4]; p6pre = lat_out[5];
       if (!P.ok) return HEP_ERR_PACK;
       int prev = p6pre, ph = L5;
       for (int l = 3; l < 5; l++) {
@@ -874,6 +920,10 @@ int build_session(Session* s, const Pack& pack, std::string* err) {
         case F_SE_SCALE: o.se.scale = (float*)ptr; break;
         case F_POOL_IN: o.pool.in = ptr; break;
         case F_POOL_OUT: o.pool.out = ptr; break;
+        case F_PWG_A: o.pwg.seg[r.seg].A = ptr; break;
+        case F_PWG_W: o.pwg.seg[r.seg].W = ptr; break;
+        case F_PWG_B: o.pwg.seg[r.seg].bias = (const float*)ptr; break;
+        case F_PWG_OUT: o.pwg.seg[r.seg].out = ptr; break;
         case F_SEG_SRC: o.segs[r.seg].src[r.idx] = ptr; break;
         case F_SEG_WDW: o.segs[r.seg].wdw = (const float*)ptr; break;
         case F_SEG_WPW: o.segs[r.seg].wpw = ptr; break;
