@@ -6,7 +6,8 @@
 #include <stdint.h>
 
 #define HEP_MAX_SRC 3
-#define SEP_MAX_TILES_N 6    // n-tiles (16 columns) per sepconv segment; wider layers are split into segments
+#define SEP_MAX_TILES_N 6    // n-tiles (16 columns) per head-output sepconv segment; wider headers are split into segments
+#define SEP_MAX_TILES_MAP 24 // n-tiles of a map-producing segment (BiFPN width <= 384): never split
 
 enum { ACT_NONE = 0, ACT_SWISH = 1, ACT_SIGMOID = 2 };
 enum { SRC_SAME = 1, SRC_UP = 2, SRC_DOWN = 3 };   // gather kinds of a BiFPN fusion input

@@ -483,7 +483,7 @@ struct Planner {
       }
       if (simple && (maps || heads)) direct = maps ? 1 : 2;
     }
-    const int chunk_cols = (direct ? TOWER_HDR_TILES : SEP_MAX_TILES_N) * 16;
+    const int chunk_cols_out = (direct ? TOWER_HDR_TILES : SEP_MAX_TILES_N) * 16;   // head outputs are split into column chunks, maps never
     int tiles_n_max = 0;
     for (size_t i = 0; i < specs.size(); i++) {
       const SegSpec& sp = specs[i];
@@ -500,7 +500,8 @@ struct Planner {
       bytes += (double)hw * hw * sp.N * (sp.out_t >= 0 ? es() : 4.0);
       flops += 2.0 * 9 * hw * hw * C + 2.0 * hw * hw * C * sp.N;
       wbytes += (double)sp.N * C * es() + 9.0 * C * 4;
-      for (int n0 = 0; n0 < sp.N; n0 += chunk_cols) {        // wide headers: one segment per 192 columns
+      const int chunk_cols = sp.out_t >= 0 ? SEP_MAX_TILES_MAP * 16 : chunk_cols_out;
+      for (int n0 = 0; n0 < sp.N; n0 += chunk_cols) {        // wide headers: one segment per chunk of columns
         const int Nc = std::min(chunk_cols, sp.N - n0);
         SepSeg sg; memset(&sg, 0, sizeof sg);
         sg.h = hw; sg.w = hw; sg.C = C; sg.nsrc = sp.nsrc; sg.pre_act = sp.pre_act;
@@ -675,7 +676,7 @@ int build_session(Session* s, const Pack& pack, std::string* err) {
       sp.N = Wf; sp.act = ACT_NONE; sp.head_out = -1; sp.col_kin = sp.col_kout = 1; sp.col_off = 0; sp.out_k = 0;
       for (int j = 0; j < sp.nsrc; j++) { sp.src[j] = srcs[j].first; sp.kind[j] = srcs[j].second; sp.fw[j] = w[j]; }
       sp.out_t = P.tensor(oname, s->levels[level], s->levels[level], Wf);
-      if (chain_on && s->levels[level] <= 8 && Wf <= SEP_MAX_TILES_N * 16) { pending.push_back(sp); pending_names.push_back(tn + conv); }
+      if (chain_on && s->levels[level] <= 8 && Wf <= SEP_MAX_TILES_MAP * 16) { pending.push_back(sp); pending_names.push_back(tn + conv); }
       else { flush(); P.add_sep(tn + conv, {sp}); }
       return sp.out_t;
     };

@@ -288,7 +288,7 @@ void sep_lds_layout(int C, int bf16, int ts, int max_cols_f32, int max_cols_map,
   a->off_atile = region;
   a->off_wdw = a->off_atile + px * (C + pad) * es;
   a->off_bias = a->off_wdw + (size_t)9 * C * 4;
-  a->lds_bytes = a->off_bias + (size_t)SEP_MAX_TILES_N * 16 * 4;
+  a->lds_bytes = a->off_bias + (size_t)SEP_MAX_TILES_MAP * 16 * 4;
 }
 
 int sep_prepare(void) {
