@@ -103,6 +103,31 @@ def test_other_widths_match_oracle(api, phi):
     s.close()
 
 
+@pytest.mark.parametrize("size,batch", [(384, 3), (640, 1)])
+def test_ragged_tiles_match_oracle(api, size, batch):
+    """Input sizes (multiples of 128, as the reference's up/down-sampling requires) whose pyramid levels are
+    not multiples of the 8x8 kernel tiles - 384: 48,24,12,6,3; 640: 80,40,20,10,5 (odd maps: one-sided SAME
+    padding of the stride-2 layers and max-pools): fp32 within 1e-3 of the oracle."""
+    phi, seed = 0, 4
+    sd = api["sd"](phi, seed)
+    x = torch.from_numpy(seeded_input((batch, 3, size, size), seed))
+    want = _named(*api["R"].forward(sd, x, phi))
+    s = api["Session"](sd, phi, size, batch, "fp32")
+    got = {k: v.float().cpu() for k, v in _named(*s.forward(x.cuda())).items()}
+    torch.cuda.synchronize()
+    for k in want:
+        assert got[k].shape == want[k].shape, k
+        err = (got[k] - want[k]).abs().max().item() / max(1.0, want[k].abs().max().item())
+        assert err <= 1e-3, f"size {size} {k}: {err:.3e}"
+    s.close()
+    s = api["Session"](sd, phi, size, batch, "bf16")
+    out = s.forward(x.cuda())
+    torch.cuda.synchronize()
+    for name, a_, b_ in zip(("regression", "classification", "rotation", "translation_raw", "hand"), out[1:], list(want.values())[:5]):
+        assert torch.isfinite(a_).all(), name
+    s.close()
+
+
 def test_bf16_forward_error_is_bounded(api):
     phi, size, batch, seed = 0, 256, 4, 0
     sd = api["sd"](phi, seed)
