@@ -4,7 +4,7 @@ One forward is a chain of ~80 small dependent launches that cannot fill the 256 
 MI355X, so a serving loop keeps several batches in flight: ``depth`` sessions (each a
 ``hep_handle`` with its own activation arena, graph and output buffers, all built from the
 same weights) take the submitted batches round-robin on ``depth`` HIP streams.  Measured at
-batch 16, phi 0, bf16: 17.8k frames/s with one batch in flight, 36.9k with four (the chip has
+batch 16, phi 0, bf16: 18.7k frames/s with one batch in flight, 39.4k with four (the chip has
 four hardware queues per process; more streams time-slice and lose).
 
     pool = InflightPool(state_dict, phi=0, size=256, max_batch=16, precision="bf16", depth=4)
