@@ -260,22 +260,32 @@ __global__ __launch_bounds__(SE_THREADS) void se_kernel(SeArgs a) {
   }
   __syncthreads();
   // reduce FC: wave w owns rows w, w+16, w+32 (sq <= 48 on every EfficientNet up to B7: rows beyond
-  // that loop again); the loads of all its rows are issued before the first is consumed
+  // that loop again).  ALL weight loads of a wave (3 rows x up to 5 steps of 256 channels) are issued
+  // before the first is consumed: one memory round trip instead of one per step.
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   constexpr int NW = SE_THREADS / 64;
+  constexpr int CIT = 5;                       // 256-channel steps held in registers (C <= 1280)
   for (int j0 = wave; j0 < a.sq; j0 += 3 * NW) {
     float s[3] = {0.f, 0.f, 0.f};
-    for (int c = lane * 4; c < a.C; c += 256) {   // C is a multiple of 8
-      f32x4 w[3];
+    for (int cb = 0; cb < a.C; cb += 256 * CIT) {
+      f32x4 w[3][CIT];
 #pragma unroll
-      for (int q = 0; q < 3; q++) {
-        const int j = j0 + q * NW;
-        w[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (j < a.sq) w[q] = *reinterpret_cast<const f32x4*>(a.wr + (int64_t)j * a.C + c);
+      for (int it = 0; it < CIT; it++)
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+          const int j = j0 + q * NW, c = cb + it * 256 + lane * 4;
+          w[q][it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          if (j < a.sq && c < a.C) w[q][it] = *reinterpret_cast<const f32x4*>(a.wr + (int64_t)j * a.C + c);
+        }
+#pragma unroll
+      for (int it = 0; it < CIT; it++) {
+        const int c = cb + it * 256 + lane * 4;
+        if (c < a.C) {
+          const f32x4 m = *reinterpret_cast<const f32x4*>(mean + c);
+#pragma unroll
+          for (int q = 0; q < 3; q++) s[q] += w[q][it][0] * m[0] + w[q][it][1] * m[1] + w[q][it][2] * m[2] + w[q][it][3] * m[3];
+        }
       }
-      const f32x4 m = *reinterpret_cast<const f32x4*>(mean + c);
-#pragma unroll
-      for (int q = 0; q < 3; q++) s[q] += w[q][0] * m[0] + w[q][1] * m[1] + w[q][2] * m[2] + w[q][3] * m[3];
     }
 #pragma unroll
     for (int q = 0; q < 3; q++) {
@@ -285,21 +295,28 @@ __global__ __launch_bounds__(SE_THREADS) void se_kernel(SeArgs a) {
       if (lane == 0 && j < a.sq) hid[j] = swishf(s[q] + a.br[j]);
     }
   }
-  __syncthreads();
-  // expand FC: 8 coalesced row loads in flight per lane
+  // expand FC: a lane's weights we[0..sq)[c] (up to SQR of them: one round trip) are in flight across the
+  // barrier that publishes the hidden vector
   const int per = (a.C + SE_SPLIT - 1) / SE_SPLIT;
   const int c0 = blockIdx.y * per, c1 = min(a.C, c0 + per);
-  for (int c = c0 + threadIdx.x; c < c1; c += SE_THREADS) {
+  constexpr int SQR = 48;
+  const int cme = c0 + threadIdx.x;
+  float wv[SQR];
+  if (cme < c1) {
+#pragma unroll
+    for (int j = 0; j < SQR; j++) wv[j] = j < a.sq ? a.we[(int64_t)j * a.C + cme] : 0.f;
+  }
+  __syncthreads();
+  if (cme < c1) {
+    float acc[4] = {a.be[cme], 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < SQR; j++) if (j < a.sq) acc[j & 3] = fmaf(wv[j], hid[j], acc[j & 3]);
+    for (int j = SQR; j < a.sq; j++) acc[j & 3] = fmaf(a.we[(int64_t)j * a.C + cme], hid[j], acc[j & 3]);
+    a.scale[(int64_t)b * a.C + cme] = sigmoidf((acc[0] + acc[1]) + (acc[2] + acc[3]));
+  }
+  for (int c = cme + SE_THREADS; c < c1; c += SE_THREADS) {        // slices wider than the workgroup (C > 4096)
     float acc[4] = {a.be[c], 0.f, 0.f, 0.f};
-    int j = 0;
-    for (; j + 8 <= a.sq; j += 8) {
-      float w[8];
-#pragma unroll
-      for (int q = 0; q < 8; q++) w[q] = a.we[(int64_t)(j + q) * a.C + c];
-#pragma unroll
-      for (int q = 0; q < 8; q++) acc[q & 3] = fmaf(w[q], hid[j + q], acc[q & 3]);
-    }
-    for (; j < a.sq; j++) acc[0] = fmaf(a.we[(int64_t)j * a.C + c], hid[j], acc[0]);
+    for (int j = 0; j < a.sq; j++) acc[j & 3] = fmaf(a.we[(int64_t)j * a.C + c], hid[j], acc[j & 3]);
     a.scale[(int64_t)b * a.C + c] = sigmoidf((acc[0] + acc[1]) + (acc[2] + acc[3]));
   }
 }
