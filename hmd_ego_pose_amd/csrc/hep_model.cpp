@@ -550,7 +550,8 @@ struct Planner {
       bool simple = o.segs.size() > 1 && !o.sep.chain && C <= 160;
       for (const SepSeg& g : o.segs) simple = simple && g.nsrc == 1 && g.kind[0] == SRC_SAME && !g.pre_act && g.fw[0] == 1.f && g.ts == 8;
       // measured on MI355X at bs16: 50 us per tower layer and 157 us for the headers against 46 / 112 us
-      // for one tile per workgroup, so the streaming kernel is opt-in (HEP_STREAM=1)
+      // for one tile per workgroup (k_sep.hip mode 1) and 16 / 28 us for k_tower.hip, so the streaming
+      // kernel is opt-in (HEP_TOWER=0 HEP_STREAM=1)
       const char* e = getenv("HEP_STREAM");
       o.sep.stream = simple && e && atoi(e) != 0;
     }
@@ -718,8 +719,8 @@ int build_session(Session* s, const Pack& pack, std::string* err) {
     if (ha.lds_bytes <= 159 * 1024 && A.head_depth <= HEAD_MAX_DEPTH) { fused_heads = true; break; }
   }
   // Measured on MI355X at bs16: the fused kernel (halo recompute, 1 workgroup per CU) takes 282 us
-  // against 240 us for D+1 per-layer launches, so the per-layer path is the default; HEP_HEAD=fused
-  // selects the fused kernel (kept parity-tested: it wins once launch boundaries get dearer).
+  // against 240 us for D+1 per-layer launches of k_sep.hip and 75 us for those of k_tower.hip, so the
+  // per-layer path is the default; HEP_HEAD=fused selects the fused kernel (kept parity-tested).
   { const char* e = getenv("HEP_HEAD"); if (!(e && !strcmp(e, "fused"))) fused_heads = false; }
   if (fused_heads) {
     const int op = P.new_op(OP_HEAD, "heads.fused");

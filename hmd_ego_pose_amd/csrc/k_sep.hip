@@ -1,4 +1,5 @@
-// k_sep.hip - fused SeparableConvBlock for the BiFPN nodes and the five head towers on gfx950:
+// k_sep.hip - fused SeparableConvBlock of the BiFPN nodes on gfx950 (and, with HEP_TOWER=0, of the head
+// layers - by default those run on k_tower.hip):
 //
 //   [ weighted fusion of 2-3 maps (nearest x2 up / zero-padded 3x3/2 max-pool gathers) + swish ]
 //     -> depthwise 3x3 SAME (no bias) -> pointwise 1x1 (+bias, BN folded) -> [swish | sigmoid]
@@ -8,22 +9,19 @@
 // `conv(feat); bn(feat); swish(feat)` / the header conv + permute/view/cat
 // (efficientdet/model.py:361-417; hmdegopose/model.py:55-90,127-156,191-228).
 //
-// One workgroup (16 waves) = one TSxTS output tile (TS = 16 on maps >= 16x16, else 8) of one
-// image of one "segment" (a node, or one (head, level, column-chunk) triple); a single launch
-// covers every segment of a layer, e.g. all 5 heads x 5 levels of a tower layer.  These maps are
-// tiny (32x32 .. 2x2 per image), so the kernel is latency-bound: the design goal is the shortest
-// dependent chain per workgroup and full-line stores.
-//   phase 0  issue the first pointwise-weight fragments (registers) and copy the depthwise
-//            weights + bias to LDS - nothing below depends on them until phase 2/3
-//   phase 1  fused (+swish) (TS+2)^2 halo of the depthwise input -> LDS (dtype), zero outside the
+// One workgroup = one 8x8 output tile of one image of one "segment" (a node, or one (head, level,
+// column-chunk) triple).  These maps are tiny (32x32 .. 2x2 per image), so the kernel is latency-bound:
+// the design goal is the shortest dependent chain per workgroup and full-line stores.
+//   phase 0  depthwise weights + bias -> LDS
+//   phase 1  fused (+swish) 10x10 halo of the depthwise input -> LDS (dtype), zero outside the
 //            map; all gather loads of an item are issued before the first is consumed
-//   phase 2  depthwise 3x3 from LDS -> MFMA operand tile [TS*TS pixels][C] in LDS
+//   phase 2  depthwise 3x3 from LDS -> MFMA operand tile [64 pixels][C] in LDS
 //   phase 3  1x1 conv as the transposed MFMA product of k_pw.hip (W fragment = A operand,
-//            pixels = B operand); (m-tile, n-tile) pairs are dealt round-robin to the 16 waves, the
-//            weight fragments run 4 deep ahead of the MFMAs in a register ring; results go to an
-//            LDS output tile (over the dead halo)
+//            pixels = B operand); (m-tile, n-tile) pairs are dealt round-robin to the waves;
+//            results go to an LDS output tile (over the dead halo)
 //   phase 4  the output tile leaves as full coalesced rows.  Head outputs land directly at their
 //            anchor offset in the [B, N_anchors, K] result (no permute / cat pass).
+// All index arithmetic is shifts, masks and compile-time divisors (see the note in the kernel).
 #include <stdlib.h>
 
 #include <type_traits>
