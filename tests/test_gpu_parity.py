@@ -68,19 +68,26 @@ def test_fp32_forward_matches_oracle_and_reference_golden(api, tag):
     s.close()
 
 
-@pytest.mark.parametrize("phi", [1, 2, 4])
+@pytest.mark.parametrize("phi", [1, 2, 4, 5])
 def test_other_widths_match_oracle(api, phi):
-    """BiFPN widths 88 / 112 / 224 (not multiples of the 32-channel MFMA k-step; 224 takes the wide-layer
-    paths of the head kernels): fp32 within 1e-3 of the oracle, bf16 finite and close.  The oracle is the
+    """BiFPN widths 88 / 112 / 224 / 288 (not multiples of the 32-channel MFMA k-step; 224 and 288 take the
+    wide-layer paths of the head kernels): fp32 within 1e-3 of the oracle, bf16 finite and close.  The oracle is the
     same code that the phi 0 / phi 3 golden vectors pin; 256x256 keeps the CPU side to seconds."""
     size, batch, seed = 256, 2, 2
     sd = api["sd"](phi, seed)
     x = torch.from_numpy(seeded_input((batch, 3, size, size), seed))
     ref = api["R"].forward(sd, x, phi)
     want = _named(*ref)
-    s = api["Session"](sd, phi, size, batch, "fp32")
-    got = {k: v.float().cpu() for k, v in _named(*s.forward(x.cuda())).items()}
-    torch.cuda.synchronize()
+    if phi >= 5:
+        # widths >= 288: the fp32 tile of the BiFPN kernel does not fit the 160 KB of LDS - refused loudly, bf16 only
+        with pytest.raises(api["capi"].HepError, match="too large"):
+            api["Session"](sd, phi, size, batch, "fp32")
+        want = {}
+    else:
+        s = api["Session"](sd, phi, size, batch, "fp32")
+        got = {k: v.float().cpu() for k, v in _named(*s.forward(x.cuda())).items()}
+        torch.cuda.synchronize()
+        s.close()
     for k in want:
         scale = max(1.0, want[k].abs().max().item())
         err = (got[k] - want[k]).abs().max().item() / scale
@@ -89,7 +96,6 @@ def test_other_widths_match_oracle(api, phi):
         # north-star configurations (phi 0 @ 256, phi 3 @ 512) sit at ~5e-5 and keep the 1e-3 gate above
         tol = 1e-3 if phi < 4 else 3e-3
         assert err <= tol, f"phi {phi} {k}: max |hip - oracle| / max(1, |oracle|) = {err:.3e}"
-    s.close()
     s = api["Session"](sd, phi, size, batch, "bf16")
     out = s.forward(x.cuda())
     torch.cuda.synchronize()
