@@ -148,7 +148,8 @@ void launch_se(const SeArgs&, hipStream_t);
 void launch_pool(const PoolArgs&, hipStream_t);
 void launch_mbf(const MbfArgs&, hipStream_t);
 #define MBF_SUM_ROWS 4            // waves of an mbf workgroup that run the depthwise phase (CC <= 64): partial-sum rows per tile
-size_t mbf_lds_layout(int Cin, int CC, int k, int s, int bf16, int has_expand, MbfArgs* a);
+size_t mbf_lds_layout(int Cin, int CC, int k, int s, int bf16, int has_expand, int max_inside, MbfArgs* a);
+int mbf_max_inside(int H, int W, int k, int s, int pad_t, int pad_l);
 int mbf_prepare(void);
 void launch_sep(const SepArgs&, hipStream_t);
 void launch_sep_stream(const SepArgs&, hipStream_t);

@@ -339,6 +339,7 @@ struct Planner {
 
     // fused front (expand -> LDS -> depthwise, k_mbf.hip) whenever its LDS tiles fit; the expanded
     // tensor then never reaches HBM.  HEP_NO_MBF=1 forces the two-kernel path (A/B measurements).
+    const int max_in = mbf_max_inside(Hin, Win, b.k, b.stride, pt, pl);   // rows of the compact input tile in LDS
     int CC = 0;
     // Measured on MI355X at bs16 (profiles/README.md): the fused kernel beats expand+depthwise on input
     // maps up to 32x32 (it expands only the tile pixels inside the image, so on the 8x8 maps the halo costs
@@ -348,7 +349,7 @@ struct Planner {
     const bool want = mode ? !strcmp(mode, "all") : Hin <= 32;
     if (want && !(mode && !strcmp(mode, "none")))
       for (int cand : {64, 32, 16})
-        if (mbf_lds_layout(b.cin, std::min(cand, b.expand ? cand : b.cexp), b.k, b.stride, s->dtype, b.expand, nullptr) <= 159 * 1024) { CC = cand; break; }
+        if (mbf_lds_layout(b.cin, std::min(cand, b.expand ? cand : b.cexp), b.k, b.stride, s->dtype, b.expand, max_in, nullptr) <= 159 * 1024) { CC = cand; break; }
     int part_t, nblk;
     if (CC) {
       if (!b.expand) CC = std::min(CC, b.cexp);
@@ -361,7 +362,7 @@ struct Planner {
       MbfArgs& m = o.mbf; memset(&m, 0, sizeof m);
       m.H = Hin; m.W = Win; m.Cin = b.cin; m.Cexp = b.cexp; m.Ho = Ho; m.Wo = Wo; m.k = b.k; m.s = b.stride;
       m.pad_t = pt; m.pad_l = pl; m.has_expand = b.expand; m.bf16 = s->dtype; m.CC = CC;
-      mbf_lds_layout(b.cin, CC, b.k, b.stride, s->dtype, b.expand, &m);
+      mbf_lds_layout(b.cin, CC, b.k, b.stride, s->dtype, b.expand, max_in, &m);
       if (b.expand) {
         const PackTensor* w = get(p + "._expand_conv.conv.weight", {b.cexp, b.cin, 1, 1});
         BnFold bn0; if (!fold_bn(pk, p + "._bn0", b.cexp, &bn0, err)) ok = false;
@@ -391,7 +392,7 @@ struct Planner {
       //  27.2 us from global memory - 25 taps per output re-read too much through L1)
       const bool lds_dw = dl ? atoi(dl) != 0 : (Hin <= 8 || (b.k == 5 && Hin <= 64));
       const int ccl = std::min(64, b.cexp);
-      if (lds_dw && mbf_lds_layout(b.cexp, ccl, b.k, b.stride, s->dtype, 0, nullptr) <= 159 * 1024) {
+      if (lds_dw && mbf_lds_layout(b.cexp, ccl, b.k, b.stride, s->dtype, 0, max_in, nullptr) <= 159 * 1024) {
         nblk = ((Ho + 7) / 8) * ((Wo + 7) / 8) * MBF_SUM_ROWS;
         snprintf(nm, sizeof nm, "b%d.se_partial", i);
         part_t = tensor(nm, 1, nblk, b.cexp, true);
@@ -401,7 +402,7 @@ struct Planner {
         MbfArgs& m = o.mbf; memset(&m, 0, sizeof m);
         m.H = Hin; m.W = Win; m.Cin = b.cexp; m.Cexp = b.cexp; m.Ho = Ho; m.Wo = Wo; m.k = b.k; m.s = b.stride;
         m.pad_t = pt; m.pad_l = pl; m.has_expand = 0; m.bf16 = s->dtype; m.CC = ccl;
-        mbf_lds_layout(b.cexp, ccl, b.k, b.stride, s->dtype, 0, &m);
+        mbf_lds_layout(b.cexp, ccl, b.k, b.stride, s->dtype, 0, max_in, &m);
         wref(op, F_MBF_WDW, wb.put_f32(wdw)); wref(op, F_MBF_BDW, wb.put_f32(bn1.shift));
         tref(op, F_MBF_IN, x, false); tref(op, F_MBF_OUT, dw_t, true); tref(op, F_MBF_PART, part_t, true);
         o.act_bytes_per_image = ((double)Hin * Win + (double)Ho * Wo) * b.cexp * es();

@@ -21,6 +21,8 @@
 // depthwise input.
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include <type_traits>
 
 #include "hep_dev.h"
@@ -324,10 +326,26 @@ extern "C" int hep_dbg_mbf_trace(unsigned long long* host, int max_waves, int en
 }
 #endif
 
-size_t mbf_lds_layout(int Cin, int CC, int k, int s, int bf16, int has_expand, MbfArgs* a) {
+// rows of the compact input tile: the most in-image pixels any 8x8-output tile of an H x W map covers
+int mbf_max_inside(int H, int W, int k, int s, int pad_t, int pad_l) {
+  const int pw = (8 - 1) * s + k;
+  auto span = [&](int n, int pad) {
+    const int no = (n + s - 1) / s;                        // output size along this axis (SAME)
+    int best = 0;
+    for (int t0 = 0; t0 < no; t0 += 8) {
+      const int i0 = t0 * s - pad, lo = std::max(0, -i0), hi = std::min(pw, n - i0);
+      best = std::max(best, hi - lo);
+    }
+    return best;
+  };
+  return span(H, pad_t) * span(W, pad_l);
+}
+
+size_t mbf_lds_layout(int Cin, int CC, int k, int s, int bf16, int has_expand, int max_inside, MbfArgs* a) {
   const size_t es = bf16 ? 2 : 4, pad = bf16 ? 8 : 4;
   const size_t pw = (size_t)(8 - 1) * s + k, pin = pw * pw;
-  size_t in_bytes = has_expand ? pin * (Cin + pad) * es : 0;
+  const size_t arows = (((size_t)std::min<int>(max_inside, (int)pin) + 31) / 32) * 32;   // phase B reads whole pairs of 16-row m-tiles
+  size_t in_bytes = has_expand ? arows * (Cin + pad) * es : 0;
   in_bytes = std::max(in_bytes, (size_t)MBF_THREADS * 9 * 4);            // phase D scratch lives there too
   in_bytes = (in_bytes + 15) & ~(size_t)15;
   const size_t e_bytes = (pin * (CC + pad) * es + 15) & ~(size_t)15;
