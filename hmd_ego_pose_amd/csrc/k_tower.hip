@@ -91,7 +91,7 @@ template <> struct Frag<false> {
 }  // namespace
 
 // LDS layout of one workgroup (4 waves), shared with tower_lds_bytes():
-//   [9*CW] f32 depthwise weights | [TOWER_BIAS_MAX] f32 bias | 4 waves x KS x 64 lanes operand fragments
+//   [9*CW] f32 depthwise weights | [BIAS] f32 bias (16 per n-tile of the widest segment) | 4 waves x KS x 64 lanes operand fragments
 //   | (when it fits in 48 KB) the segment's pointwise weights, rows padded against bank conflicts
 //   | (when they fit in 40 KB) the 6x6-pixel input halos of the 4 waves
 template <bool BF16, int CW, bool HDR> struct TowerCfg {
@@ -103,7 +103,8 @@ template <bool BF16, int CW, bool HDR> struct TowerCfg {
   static constexpr bool WLDS = (size_t)WROWS * WP * ES <= 48 * 1024;
   static constexpr int HP = CW + 16 / ES;                             // halo pixel pitch (elements): +16 bytes
   static constexpr bool HALO = (size_t)4 * 36 * HP * ES <= 40 * 1024;  // the 6x6-pixel halos of 4 waves fit
-  static constexpr size_t OFF_XA = ((size_t)9 * CW + TOWER_BIAS_MAX) * 4;
+  static constexpr int BIAS = WROWS;                                  // bias floats staged per segment (one per weight row)
+  static constexpr size_t OFF_XA = ((size_t)9 * CW + BIAS) * 4;
   static constexpr size_t OFF_W = OFF_XA + (size_t)4 * KS * 64 * 16;
   static constexpr size_t OFF_HALO = OFF_W + (WLDS ? (size_t)WROWS * WP * ES : 0);
   static constexpr size_t LDS = OFF_HALO + (HALO ? (size_t)4 * 36 * HP * ES : 0);
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(256, BF16 ? 4 : 2) void tower_kernel(const SepSeg* 
   // (every load of the staging is issued before the first LDS store: one memory round trip, not one per
   //  loop iteration)
   {
-    constexpr int NDW = (9 * CW / 4 + 255) / 256, NB = (TOWER_BIAS_MAX / 4 + 255) / 256;
+    constexpr int NDW = (9 * CW / 4 + 255) / 256, NB = (Cfg::BIAS / 4 + 255) / 256;
     constexpr int VPR = CW / KL, NW = WLDS ? (Cfg::WROWS * VPR + 255) / 256 : 0;
     const GLOBAL f32x4* gdw = (const GLOBAL f32x4*)sg->wdw;
     const GLOBAL f32x4* gb = (const GLOBAL f32x4*)sg->bias;
