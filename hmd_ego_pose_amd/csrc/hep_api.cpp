@@ -279,6 +279,18 @@ int hep_anchors(int size, float* anchors, float* translation_anchors) {
   return n;
 }
 
+int hep_preprocess_u8_device(hep_handle* h, const uint8_t* rgb_hwc, int batch, int height, int width, float* out_hwc, void* stream) {
+  if (!h || !rgb_hwc || !out_hwc || batch < 1 || height < 1 || width < 1) return fail(HEP_ERR_INVALID, "bad argument");
+  Session& s = h->s;
+  if (std::max(height, width) != s.size)
+    return fail(HEP_ERR_UNSUPPORTED, "preprocess: max(height, width) must equal the network size (cv2.resize bilinear is parity-unpinned and not implemented)");
+  HIPRET(hipSetDevice(s.device));
+  PreprocArgs a; a.in = rgb_hwc; a.out = out_hwc; a.B = batch; a.H = height; a.W = width; a.S = s.size;
+  launch_preprocess(a, (hipStream_t)stream);
+  HIPRET(hipGetLastError());
+  return 0;
+}
+
 int hep_decode_device(hep_handle* h, const float* regression, const float* translation_raw, const float* camera, int batch,
                       float* boxes, float* translation, void* stream) {
   if (!h || !camera || !boxes || !translation) return fail(HEP_ERR_INVALID, "bad argument");

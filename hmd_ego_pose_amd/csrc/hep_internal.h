@@ -127,6 +127,9 @@ struct DecodeArgs {
   int B, N; float clip_max;
 };
 
+// ---- preprocess (no-resize case): uint8 RGB HWC -> normalised float32 HWC, zero-padded to S x S ----
+struct PreprocArgs { const uint8_t* in; float* out; int B, H, W, S; };
+
 // ---- feature export: NHWC dtype -> NCHW fp32 ----
 struct ExportArgs { const void* in; float* out; int B, H, W, C, bf16; };
 
@@ -165,6 +168,7 @@ void head_lds_layout(int C, int depth, int ts, int bf16, int chunk, HeadArgs* a)
 int head_prepare(void);
 void launch_decode(const DecodeArgs&, hipStream_t);
 void launch_export(const ExportArgs&, hipStream_t);
+void launch_preprocess(const PreprocArgs&, hipStream_t);
 void launch_filter(const FilterArgs&, hipStream_t);
 int dw_blocks_per_image(int Ho, int Wo, int C, int TW);
 void sep_lds_layout(int C, int bf16, int ts, int max_cols_f32, int max_cols_map, SepArgs* a);

@@ -164,3 +164,32 @@ __global__ __launch_bounds__(FILTER_THREADS) void filter_kernel(FilterArgs a) {
 void launch_filter(const FilterArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(filter_kernel, dim3(a.B), dim3(FILTER_THREADS), 0, s, a);
 }
+
+// ------------------------------------------------------------------------------------------------
+// preprocess_image for images that need no resize (reference generators/colibri_common.py:622-656 with
+// scale == 1, i.e. max(H, W) == network size - every 256x256 syn_colibri frame): uint8 RGB [B,H,W,3] ->
+// float32 [B,S,S,3], `image.astype(float32); image /= 255.; image -= mean; image /= std`, zero-padded at the
+// bottom / right.  numpy evaluates the two in-place operations with the float64 lists in double and rounds
+// the result to float32 each time; the kernel does exactly that, so the output is bit-identical.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void preprocess_kernel(PreprocArgs a) {
+  const int64_t total = (int64_t)a.B * a.S * a.S * 3;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int c = (int)(idx % 3);
+  const int64_t p = idx / 3;
+  const int x = (int)(p % a.S), y = (int)((p / a.S) % a.S), b = (int)(p / ((int64_t)a.S * a.S));
+  float v = 0.f;
+  if (y < a.H && x < a.W) {
+    const double mean[3] = {0.485, 0.456, 0.406}, sd[3] = {0.229, 0.224, 0.225};
+    const float r1 = __fdiv_rn((float)a.in[(((int64_t)b * a.H + y) * a.W + x) * 3 + c], 255.0f);
+    const float r2 = (float)((double)r1 - mean[c]);
+    v = (float)((double)r2 / sd[c]);
+  }
+  a.out[idx] = v;
+}
+
+void launch_preprocess(const PreprocArgs& a, hipStream_t s) {
+  const int64_t total = (int64_t)a.B * a.S * a.S * 3;
+  hipLaunchKernelGGL(preprocess_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+}

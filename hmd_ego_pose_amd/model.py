@@ -89,6 +89,19 @@ class Session:
                                                _capi.ptr_array(feats) if feats else None, stream))
         return (tuple(feats) if feats else None, *outs)
 
+    def preprocess(self, images_u8: torch.Tensor) -> torch.Tensor:
+        """uint8 RGB [B,H,W,3] on the device with max(H, W) == size -> the NCHW view of the normalised, zero-padded
+        float32 [B,size,size,3] (generators/colibri_common.py:622-656; the view is what eval/common.py:397 feeds
+        the model and ``forward`` reads in place).  Frames that would need a resize are refused."""
+        if not images_u8.is_cuda or images_u8.dtype != torch.uint8 or images_u8.dim() != 4 or images_u8.shape[3] != 3:
+            raise ValueError("expected a uint8 ROCm tensor [B,H,W,3]")
+        x = images_u8.contiguous()
+        B, H, W = x.shape[0], x.shape[1], x.shape[2]
+        out = torch.empty((B, self.size, self.size, 3), dtype=torch.float32, device=x.device)
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        _capi.check(_capi.lib().hep_preprocess_u8_device(self.handle, x.data_ptr(), B, H, W, out.data_ptr(), stream))
+        return out.permute(0, 3, 1, 2)
+
     def decode(self, regression, translation_raw, camera):
         B = regression.shape[0]
         boxes = torch.empty((B, self.num_anchors, 4), dtype=torch.float32, device=regression.device)

@@ -128,6 +128,15 @@ int hep_filter_device(hep_handle* h, const float* boxes, const float* classifica
                       int32_t* det_labels, float* det_rotation, float* det_translation, float* det_hand,
                       int32_t* det_index, int32_t* det_count, void* stream);
 
+/* preprocess_image for frames that need no resize (reference generators/colibri_common.py:622-656 with
+ * max(height, width) == size, i.e. scale 1.0 - every 256x256 syn_colibri frame): device uint8 RGB
+ * [batch, height, width, 3] -> device float32 [batch, size, size, 3] = ((x / 255) - mean) / std, zero-padded at
+ * the bottom / right, bit-identical to the numpy code.  Hand the result to hep_run_device as the NCHW view of
+ * NHWC memory (strides {size*size*3, 1, size*3, 3}), exactly what eval/common.py:397 does.  Other sizes need
+ * cv2.resize (bilinear on uint8: parity unpinned) and are refused with HEP_ERR_UNSUPPORTED. */
+int hep_preprocess_u8_device(hep_handle* h, const uint8_t* rgb_hwc, int batch, int height, int width,
+                             float* out_hwc, void* stream);
+
 /* Introspection used by tests, bench.py and DESIGN.md tables. */
 int hep_debug_tensor_count(const hep_handle* h);
 int hep_debug_tensor_info(const hep_handle* h, int i, const char** name, int64_t dims[4] /* B,H,W,C */);

@@ -195,3 +195,24 @@ def add_s_metric(points, diameter, R_gt, t_gt, R_pr, t_pr, thr=0.1, max_points=1
     dmin = np.sqrt(d2.astype(np.float64)).astype(np.float32).min(axis=1)
     d = float(np.mean(dmin))
     return d <= diameter * thr, d
+
+
+def preprocess_image(image: np.ndarray, image_size: int):
+    """generators/colibri_common.py:622-656 for frames that need no resize (max(H, W) == image_size, scale 1.0:
+    cv2.resize to the same size returns the image unchanged).  The arithmetic lines are the reference's own:
+    uint8 HWC RGB -> float32, /255., -mean, /std (numpy evaluates the two list operands in float64 and rounds
+    the in-place result to float32), zero-pad bottom/right.  Returns (image [S,S,3] float32, scale)."""
+    image_height, image_width = image.shape[:2]
+    if max(image_height, image_width) != image_size:
+        raise ValueError("resize needed: cv2.resize (bilinear, uint8) is parity-unpinned and not restated")
+    scale = image_size / max(image_height, image_width)
+    image = image.astype(np.float32)
+    image /= 255.
+    mean = [0.485, 0.456, 0.406]
+    std = [0.229, 0.224, 0.225]
+    image -= mean
+    image /= std
+    pad_h = image_size - image_height
+    pad_w = image_size - image_width
+    image = np.pad(image, [(0, pad_h), (0, pad_w), (0, 0)], mode='constant')
+    return image, scale

@@ -6,6 +6,7 @@ lower index)."""
 import math
 
 import numpy as np
+import pytest
 
 from oracle import decode_ref as D
 
@@ -101,3 +102,19 @@ def test_decode_boxes_properties():
     tr = D.decode_translation(ta, raw, cam)[0]
     centre = np.nonzero((ta[:, 0] == 132) & (ta[:, 1] == 132))[0]
     assert len(centre) > 0 and np.all(tr[centre, :2] == 0) and np.all(tr[:, 2] == 500)
+
+
+def test_preprocess_image_restatement():
+    """Known answers of the reference's preprocess arithmetic (colibri_common.py:633-651): pixel value 0 ->
+    -mean/std, 255 -> (1-mean)/std per channel in float32; padding rows/columns are exactly zero."""
+    from oracle import decode_ref as D
+    img = np.zeros((200, 256, 3), np.uint8)
+    img[1, 2] = 255
+    out, scale = D.preprocess_image(img, 256)
+    assert out.shape == (256, 256, 3) and out.dtype == np.float32 and scale == 1.0
+    mean, std = np.array([0.485, 0.456, 0.406]), np.array([0.229, 0.224, 0.225])
+    assert np.array_equal(out[0, 0], ((np.float32(0) - mean).astype(np.float32) / std).astype(np.float32))
+    assert np.array_equal(out[1, 2], ((np.float32(1) - mean).astype(np.float32) / std).astype(np.float32))
+    assert not out[200:].any()
+    with pytest.raises(ValueError):
+        D.preprocess_image(np.zeros((100, 100, 3), np.uint8), 256)

@@ -312,3 +312,25 @@ def test_inflight_pool_matches_single_session():
                      ("boxes", boxes), ("translation", trans)):
             assert r[k].shape == t.shape and torch.equal(r[k], t), k
     pool.close(); ref.close()
+
+
+def test_preprocess_is_bit_exact_and_feeds_the_forward(api):
+    """uint8 frames -> hep_preprocess_u8_device == the reference's numpy arithmetic bit for bit (no-resize case,
+    incl. bottom/right zero padding); its NHWC-memory NCHW view goes straight into the forward."""
+    size = 256
+    s = api["Session"](api["sd"](0, 0), 0, size, 4, "fp32")
+    rng = np.random.Generator(np.random.PCG64(11))
+    for (h, w) in ((256, 256), (200, 256), (256, 131)):
+        img = rng.integers(0, 256, (3, h, w, 3), dtype=np.uint8)
+        img[0, 0, 0] = (0, 255, 128)
+        want = np.stack([api["D"].preprocess_image(f, size)[0] for f in img])
+        got = s.preprocess(torch.from_numpy(img).cuda())
+        assert got.shape == (3, 3, size, size) and not got.is_contiguous()
+        assert np.array_equal(got.permute(0, 2, 3, 1).cpu().numpy(), want), (h, w)
+    a = s.forward(got)
+    b = s.forward(got.contiguous())
+    for u, v in zip(a[1:], b[1:]):
+        assert torch.equal(u, v)
+    with pytest.raises(api["capi"].HepError, match="preprocess"):
+        s.preprocess(torch.zeros((1, 128, 128, 3), dtype=torch.uint8, device="cuda"))
+    s.close()
