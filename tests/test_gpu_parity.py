@@ -334,3 +334,38 @@ def test_preprocess_is_bit_exact_and_feeds_the_forward(api):
     with pytest.raises(api["capi"].HepError, match="preprocess"):
         s.preprocess(torch.zeros((1, 128, 128, 3), dtype=torch.uint8, device="cuda"))
     s.close()
+
+
+def test_host_api_is_reentrant_from_threads(api):
+    """Session.Run replacement semantics: hep_run on ONE handle may be re-entered from several host threads (the
+    WebRTC frame callbacks of unity-sandbox/WebRTCNetCoreSandbox/Program.cs:128 do) - calls are serialised per
+    handle and every caller gets the result of its own frame; separate handles run concurrently."""
+    import threading
+    capi = api["capi"]
+    lib = capi.lib()
+    phi, size = 0, 256
+    sd = api["sd"](phi, 2)
+    handles = [api["Session"](sd, phi, size, 1, "fp32") for _ in range(2)]
+    N = handles[0].num_anchors
+    frames = [seeded_input((1, 3, size, size), 20 + i) for i in range(6)]
+
+    def run(sess, x):
+        outs = [np.empty((1, N, k), np.float32) for k in (4, 1, 3, 3, 63)]
+        capi.check(lib.hep_run(sess.handle, x.ctypes.data, 1, None, *[o.ctypes.data for o in outs]))
+        return outs
+
+    want = [run(handles[0], f) for f in frames]                       # serial reference
+    got = [None] * len(frames) * 2
+
+    def worker(slot, sess, f):
+        for _ in range(3):
+            got[slot] = run(sess, f)
+
+    threads = [threading.Thread(target=worker, args=(i, handles[0], frames[i])) for i in range(len(frames))]
+    threads += [threading.Thread(target=worker, args=(len(frames) + i, handles[1], frames[i])) for i in range(len(frames))]
+    for t in threads: t.start()
+    for t in threads: t.join()
+    for i in range(len(frames)):
+        for a_, b_, c_ in zip(want[i], got[i], got[len(frames) + i]):
+            assert np.array_equal(a_, b_) and np.array_equal(a_, c_), i
+    for h in handles: h.close()
