@@ -93,8 +93,12 @@ int hep_run(hep_handle* h, const float* input_nchw, int batch, float* const feat
 /* HMDEgoPose.forward on device memory, asynchronous on `stream` (a hipStream_t; NULL = default).
  * in_strides: element strides of (n,c,h,w) - an NHWC-memory view (eval/common.py:397) is accepted
  * as is; NULL = contiguous NCHW.  outs[5] = regression, classification, rotation, translation_raw,
- * hand (device, fp32, required).  feats may be NULL.  Re-running with the same pointers replays
- * one hipGraph. */
+ * hand (device, fp32; NULL = leave them in the handle's own buffers, read back through
+ * hep_decode_device / hep_filter_device with NULL inputs).  feats may be NULL.  Every batch size replays
+ * its own hipGraph.
+ * A handle owns ONE activation arena: work enqueued through it is stream-ordered, so use a handle on one
+ * stream at a time (or let the previous forward finish before switching streams).  For several batches in
+ * flight create several handles from the same weight pack - see INTEGRATION.md section 4. */
 int hep_run_device(hep_handle* h, const float* input, const int64_t in_strides[4], int batch,
                    float* const outs[5], float* const feats[5], void* stream);
 
