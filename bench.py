@@ -212,6 +212,11 @@ def main():
                                "graph_replay_ms": round(total_ms, 4), "event_overhead_us_subtracted": round(ev_overhead * 1e3, 2),
                                "whole_step_algorithmic_GBps": round(step_bytes / (ms * 1e-3) / 1e9, 1),
                                "end_to_end_frac": round(step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            # context for the block above: the next device functions by total time, same definitions
+            out["roofline"]["top"] = [
+                {"kernel": k, "launches_per_step": v[3], "avg_launch_us": round(v[0] / v[3] * 1e3, 2), "share_of_step": round(v[0] / sum(per), 3),
+                 "achieved": round(v[1] / (v[0] * 1e-3) / 1e9, 1), "frac": round(v[1] / (v[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:5]]
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(phi, S)
         print(json.dumps(out), flush=True)
