@@ -468,10 +468,18 @@ struct Planner {
     int out_t;                       // dtype tensor, or -1 for a head output
     int head_out; int col_kin, col_kout, col_off, out_k;   // head output index 0..4 and column mapping
   };
+  int sep_tile_side() const {
+    SepArgs probe; memset(&probe, 0, sizeof probe);
+    sep_lds_layout(s->arch.fpn_w, s->dtype, 8, 96, s->arch.fpn_w, &probe);
+    return probe.lds_bytes > 160 * 1024 ? 4 : 8;
+  }
   void add_sep(const std::string& name, const std::vector<SegSpec>& specs, bool chain = false) {
     const int C = s->arch.fpn_w;
     const int op = new_op(OP_SEP, name);
-    int tile_begin = 0, ts_max = 8, cols_f32 = 0, cols_map = 0;
+    int tile_begin = 0, ts_max = 4, cols_f32 = 0, cols_map = 0;
+    // tile side 8; 4 where the 8x8 tile of this width and dtype does not fit in LDS (fp32, width >= 288);
+    // chains (one tile per image) then only cover levels <= 4x4
+    const int ts_pick = sep_tile_side();
     double bytes = 0, flops = 0, wbytes = 0;
     // head layers (many independent single-source segments, all maps or all head outputs) run on the
     // wave-per-patch kernel of k_tower.hip; HEP_TOWER=0 keeps them on the tiled kernel of k_sep.hip
@@ -526,7 +534,7 @@ struct Planner {
           bf[n] = bp->data[n0 + n] * sc + sh;
         }
         sg.N = Nc; sg.tilesN = tilesN; sg.act = sp.act; sg.n_base = n0;
-        sg.ts = 8;   // 16x16 tiles measured slower (3 dependent gather rounds per lane, 1 workgroup per CU)
+        sg.ts = ts_pick;   // 8; 16x16 tiles measured slower (3 dependent gather rounds per lane, 1 workgroup per CU)
         ts_max = std::max(ts_max, sg.ts);
         if (sp.out_t >= 0) cols_map = std::max(cols_map, Nc); else cols_f32 = std::max(cols_f32, Nc);
         sg.tiles_x = (hw + sg.ts - 1) / sg.ts; sg.tiles_y = sg.tiles_x; sg.tile_begin = tile_begin;
@@ -680,7 +688,7 @@ int build_session(Session* s, const Pack& pack, std::string* err) {
       sp.N = Wf; sp.act = ACT_NONE; sp.head_out = -1; sp.col_kin = sp.col_kout = 1; sp.col_off = 0; sp.out_k = 0;
       for (int j = 0; j < sp.nsrc; j++) { sp.src[j] = srcs[j].first; sp.kind[j] = srcs[j].second; sp.fw[j] = w[j]; }
       sp.out_t = P.tensor(oname, s->levels[level], s->levels[level], Wf);
-      if (chain_on && s->levels[level] <= 8 && Wf <= SEP_MAX_TILES_MAP * 16) { pending.push_back(sp); pending_names.push_back(tn + conv); }
+      if (chain_on && s->levels[level] <= P.sep_tile_side() && Wf <= SEP_MAX_TILES_MAP * 16) { pending.push_back(sp); pending_names.push_back(tn + conv); }
       else { flush(); P.add_sep(tn + conv, {sp}); }
       return sp.out_t;
     };

@@ -9,7 +9,7 @@
 // `conv(feat); bn(feat); swish(feat)` / the header conv + permute/view/cat
 // (efficientdet/model.py:361-417; hmdegopose/model.py:55-90,127-156,191-228).
 //
-// One workgroup = one 8x8 output tile of one image of one "segment" (a node, or one (head, level,
+// One workgroup = one 8x8 output tile (4x4 where the fp32 tile of a wide layer would not fit in LDS) of one image of one "segment" (a node, or one (head, level,
 // column-chunk) triple).  These maps are tiny (32x32 .. 2x2 per image), so the kernel is latency-bound:
 // the design goal is the shortest dependent chain per workgroup and full-line stores.
 //   phase 0  depthwise weights + bias -> LDS
@@ -152,11 +152,11 @@ __global__ __launch_bounds__(SEP_THREADS_OF(MODE), MODE == 1 ? SEP_M1_WAVES : 4)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, g = lane >> 4;
   const int rows_valid = min(TS, h - y0), cols_valid = min(TS, w - x0);
-  const int mtv = TS == 16 ? rows_valid : (rows_valid + 1) >> 1;   // 16-pixel m-tiles holding a valid pixel
+  const int mtv = TS == 16 ? rows_valid : (TS == 8 ? (rows_valid + 1) >> 1 : 1);   // 16-pixel m-tiles holding a valid pixel (TS 4: the whole tile)
   const int ksteps = (C + KSTEP - 1) / KSTEP;
   const T* W = reinterpret_cast<const T*>(sg.wpw);
   int cgsh = 0; while ((1 << cgsh) < CG) cgsh++;
-  const int tssh = TS == 16 ? 4 : 3;
+  const int tssh = TS == 16 ? 4 : (TS == 8 ? 3 : 2);
   // ---- phase 0: depthwise weights + bias to LDS (independent of the activations) ----
   for (int i = threadIdx.x; i < 9 * C; i += SEP_THREADS) wdw_s[i] = sg.wdw[i];
   for (int i = threadIdx.x; i < sg.tilesN * 16; i += SEP_THREADS) bias_s[i] = sg.bias[i];
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(SEP_THREADS_OF(MODE), MODE == 1 ? SEP_M1_WAVES : 4)
     const int cg = threadIdx.x & ((1 << cgsh) - 1);
     if (cg < CG)
       for (int pos = threadIdx.x >> cgsh; pos < ((a.dbg_skip & 1) ? 0 : HS * HS); pos += SEP_THREADS >> cgsh) {
-        const int hy = TS == 16 ? pos / 18 : pos / 10, hx = pos - hy * HS;
+        const int hy = TS == 16 ? pos / 18 : (TS == 8 ? pos / 10 : pos / 6), hx = pos - hy * HS;
         const int y = y0 + hy - 1, x = x0 + hx - 1;
         float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (y >= 0 && y < h && x >= 0 && x < w) gather_fuse<BF16>(sg, b, y, x, cg * 8, v);
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(SEP_THREADS_OF(MODE), MODE == 1 ? SEP_M1_WAVES : 4)
     const int npx = rows_valid * cols_valid;
     for (int pp = wave; pp < npx; pp += SEP_WAVES) {
       const int py = pp / cols_valid, px = pp % cols_valid;
-      const int m = TS == 16 ? py * 16 + px : py * 8 + px;
+      const int m = py * TS + px;
       float* orow = o + ((int64_t)(y0 + py) * w + x0 + px) * sg.out_rowstride;
       for (int c = lane; c < Nc; c += 64) {
         const int nn = c + sg.n_base;

@@ -29,7 +29,8 @@ _ALIGN = 64
 # amplitude multipliers on top of N(0, 1/fan_in), per conv role; fixed constants tuned once so
 # that seeded activations stay O(1) AND input-dependent through every stage (see tests/golden)
 GAINS = {"stem": 1.0, "expand": 1.5, "dw": None, "project": 1.0, "se": 1.0, "sep_dw": 1.35, "sep_pw": 1.2, "lateral": 1.0}
-_DW_GAIN_OF_PHI = [1.85, 1.8, 1.75, 1.7, 1.65, 1.45, 1.6, 1.6]   # deeper backbones need less (0..5 tuned; golden vectors exist for 0 and 3)
+_DW_GAIN_OF_PHI = [1.85, 1.8, 1.75, 1.7, 1.65, 1.45, 1.35, 1.35]   # deeper backbones need less (0..6 tuned; golden vectors exist for 0 and 3)
+_SEP_GAIN_OF_PHI = [1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 0.8, 0.8]       # 8 BiFPN cells + 5-layer heads of phi 6 need less in the separable convs
 
 
 def strip_checkpoint_prefix(state: Mapping[str, torch.Tensor]) -> "OrderedDict[str, torch.Tensor]":
@@ -93,6 +94,8 @@ def seeded_state_dict(phi: int, seed: int = 0, gain: float = 1.0) -> "OrderedDic
             a = rng.standard_normal(shape) * np.sqrt(gain / fan_in)
             role = _conv_role(key)
             a = a * (GAINS[role] if GAINS[role] is not None else _DW_GAIN_OF_PHI[phi])
+            if role in ("sep_dw", "sep_pw"):
+                a = a * _SEP_GAIN_OF_PHI[phi]
         elif kind in ("conv_b", "bn_b", "mean"):
             a = rng.standard_normal(shape) * 0.1
         elif kind in ("bn_w", "var"):
