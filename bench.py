@@ -1,26 +1,35 @@
 #!/usr/bin/env python3
 """bench.py - frames/sec of the MI355X EfficientPose path at 256x256, batch 16 per GPU, phi 0.
 
-    python bench.py [--gpus N --steps K --warmup W]           (N=1)
+    python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
+
+With --gpus N > 1 and no torchrun environment the script starts its N rank processes itself (fresh
+children, started before anything touches a GPU) and relays rank 0's line.
 
 One step = one pass of the hot path over one batch of 16 synthetic, HBM-resident frames per
 GPU: the full forward (stem .. heads, one hipGraph replay) + box/translation decode, through
 the C ABI of libhep.so.  --inflight D (default 4) keeps D steps in flight on D HIP streams (D
-sessions): a single forward is a dependent chain of ~90 small kernels and leaves most of the
-256 CUs idle; `one_batch_in_flight` reports the strictly sequential number as well.  Weak scaling: every rank owns 16 frames, the forward needs no
-collective (frames are independent); ranks meet only at the timing barriers.  Rank 0 prints
-ONE JSON line.  At N=1 it also carries
-  roofline      the dominant device function: algorithmic bytes per launch / its in-sequence
+sessions): a single forward is a dependent chain of small kernels and leaves most of the
+256 CUs idle; `one_batch_in_flight` reports the strictly sequential number as well.  Weak scaling:
+every rank owns 16 frames, the forward needs no collective (frames are independent); ranks meet
+only at the timing barriers.  Rank 0 prints ONE JSON line.  It also carries
+  comm          the serving loop around the same step with the data movement SURVEY 8(e) describes:
+                rank 0 owns the global batch of uint8 frames and scatters 16 to every rank (point to point
+                over RCCL/xGMI), each rank runs preprocess -> forward -> decode -> detection filter, and the
+                post-filter rows are gathered on rank 0; frames/s with all of that inside the timed loop
+  roofline      (N=1) the dominant device function: algorithmic bytes per launch / its in-sequence
                 launch duration measured here with HIP events, against 8 TB/s HBM3E
-  cpu_baseline  the CPU oracle (torch fp32 restatement of the reference) timed on the host
+  cpu_baseline  (N=1) the CPU oracle (torch fp32 restatement of the reference) timed on the host
                 cores in the evaluate.py regime (batch 1, anchors rebuilt per call, decode).
 """
 import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,6 +38,7 @@ sys.path.insert(0, ROOT)
 
 METRIC = "frames/sec at 256x256 bs16 EfficientPose-phi0; ADD(-S) vs ref"
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (spec); ~6.3 TB/s achievable
+PRECISIONS = ["bf16", "fp32", "fp8"]
 
 
 def cpu_baseline(phi, size, budget_s=15.0):
@@ -94,7 +104,7 @@ def pmc_traffic(symbol):
     return None
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -102,12 +112,37 @@ def main():
     ap.add_argument("--batch", type=int, default=16, help="frames per GPU per step")
     ap.add_argument("--phi", type=int, default=0)
     ap.add_argument("--size", type=int, default=256)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=PRECISIONS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-comm", action="store_true", help="skip the scatter -> preprocess -> forward -> filter -> gather loop")
+    ap.add_argument("--comm-score-threshold", type=float, default=0.5)
     ap.add_argument("--inflight", type=int, default=4, help="batches in flight per GPU (sessions on separate HIP streams)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for wiring tests)")
     ap.add_argument("--single-device", action="store_true", help="wiring test: every rank uses cuda:0 (needs --backend gloo)")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def self_launch(args):
+    """--gpus N without a torchrun environment: start N rank processes of this script (one per GPU, env as
+    torchrun sets it) and relay their output.  This parent never initialises a GPU and never exec()s."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
 
     import numpy as np
     import torch
@@ -122,6 +157,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the product path")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: local rank {local_rank} but only {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     B, S, phi = args.batch, args.size, args.phi
@@ -130,7 +167,7 @@ def main():
     sd = hd.broadcast_state_dict(seeded_state_dict(phi, 0), dev)
     D = max(1, args.inflight)
     # D sessions = D batches in flight on D HIP streams: the forward of one batch is a dependent chain of
-    # ~90 small kernels that cannot fill 256 CUs, so a serving loop keeps several batches in flight
+    # small kernels that cannot fill 256 CUs, so a serving loop keeps several batches in flight
     # (step i runs on slot i % D; every step is a full forward + decode of its own 16 frames)
     sess = [Session(sd, phi, S, B, args.precision, dev) for _ in range(D)]
     streams = [torch.cuda.Stream(dev) for _ in range(D)]
@@ -164,6 +201,40 @@ def main():
     elapsed = hd.max_over_ranks(time.perf_counter() - t0, dev)
     assert all(torch.isfinite(t).all() for t in boxes) and all(torch.isfinite(t).all() for t in trans)
 
+    # ---- the same step inside a serving loop with its data movement: scatter of uint8 frames from
+    #      rank 0, preprocess, forward, decode, detection filter, gather of the post-filter rows on rank 0 ----
+    comm = None
+    if not args.no_comm:
+        G = B * world
+        M = 100
+        frames_u8 = torch.from_numpy(np.random.Generator(np.random.PCG64(7)).integers(0, 256, (G, S, S, 3), dtype=np.uint8)).to(dev) if rank == 0 else None
+
+        def serve():
+            mine = hd.scatter_frames(frames_u8, G, (S, S, 3), dev, dtype=torch.uint8)       # 196 KB per frame instead of 786 KB fp32
+            x = sess[0].preprocess(mine)                                                  # NCHW view of normalised NHWC memory
+            _, reg, cls, rot, trn, hand = sess[0].forward(x, want_features=False)
+            bx, tr = sess[0].decode(reg, trn, cam)
+            det = sess[0].filter(bx, cls, rot, tr, hand, args.comm_score_threshold, 0.5, M)
+            return hd.gather_detections(det, G)
+
+        for _ in range(3):
+            got = serve()
+        torch.cuda.synchronize(dev); hd.barrier()
+        k2 = max(10, args.steps // 4)
+        t1 = time.perf_counter()
+        for _ in range(k2):
+            got = serve()
+        torch.cuda.synchronize(dev); hd.barrier()
+        e2 = hd.max_over_ranks(time.perf_counter() - t1, dev)
+        if rank == 0:
+            assert got["count"].shape[0] == G and got["boxes"].shape == (G, M, 4)
+            row_bytes = M * (4 + 1 + 1 + 3 + 3 + 63 + 1) * 4 + 4
+            comm = {"value": round(G * k2 / e2, 2), "unit": "frames/s", "ms_per_step": round(e2 / k2 * 1e3, 4), "steps": k2,
+                    "what": "one batch in flight per GPU: scatter uint8 frames from rank 0 (point to point) -> preprocess -> forward -> decode -> "
+                            f"filter (score > {args.comm_score_threshold}, NMS 0.5, top {M}) -> gather detection rows on rank 0",
+                    "scatter_bytes_per_step": int((G - B) * S * S * 3), "gather_bytes_per_step": int((G - B) * row_bytes),
+                    "backend": args.backend if world > 1 else None, "mean_detections_per_frame": round(float(got["count"].float().mean()), 1)}
+
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         out = {
@@ -177,6 +248,8 @@ def main():
                        "phi": phi, "size": S, "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
                        "batches_in_flight": D, "anchors": N, "launches_per_step": len(sess[0].kernels(B)) + 1},
         }
+        if comm is not None:
+            out["comm"] = comm
         if world == 1:
             # the strictly sequential number (one batch in flight): latency of a step
             for i in range(10):

@@ -4,9 +4,9 @@ Host-side description of *what* the network is for a compound coefficient
 ``phi``: the MBConv block list, BiFPN width/repeats, head depth, pyramid
 geometry and the ordered parameter inventory (names + shapes) that the
 reference's ``state_dict`` uses.  ``csrc/hep_model.cpp`` holds the same tables
-in C++ (the C-ABI library is self-contained); ``tests/test_arch.py`` checks the
-two against each other and against the golden key list captured from the
-reference.
+in C++ (the C-ABI library is self-contained); ``tests/test_host_cpu.py`` checks
+this table against the golden key list captured from the reference, and the GPU
+parity tests exercise the C++ copy.
 
 Reference behaviour restated here (not copied):
   * per-phi tables ............ pytorch-sandbox/backbone.py:22-43

@@ -28,7 +28,6 @@ Session::~Session() {
   for (auto& g : graphs) for (hipGraphExec_t ge : g.second) hipGraphExecDestroy(ge);
   for (auto& lo : lane_ops) for (Op& o : lo) {
     if (o.kind == OP_SEP) { hipFree((void*)o.sep.segs); hipFree((void*)o.sep.tile_seg); }
-    if (o.kind == OP_HEAD) { hipFree((void*)o.head.segs); hipFree((void*)o.head.tile_seg); }
   }
   for (hipStream_t st : lane_streams) hipStreamDestroy(st);
   for (hipEvent_t ev : lane_events) hipEventDestroy(ev);
@@ -37,23 +36,11 @@ Session::~Session() {
   for (int i = 0; i < 5; i++) { hipFree(d_out[i]); hipFree(d_feat_nchw[i]); }
   hipFree(d_in); hipFree(d_anchors); hipFree(d_tanchors); hipFree(d_boxes); hipFree(d_trans); hipFree(d_cam);
   hipFree(d_keys); hipFree(d_det);
+  for (int i = 0; i < 5; i++) hipFree(d_stage[i]);
   if (stream) hipStreamDestroy(stream);
 }
 
 void launch_op(const Session& s, const Op& op, int batch, hipStream_t st, const float* in, const int64_t* strides) {
-  // HEP_SKIP_OPS=<substring>[,<substring>..]: leave out the launches whose name matches (removal experiments
-  // for timing only - the results are garbage)
-  static const char* skip = getenv("HEP_SKIP_OPS");
-  if (skip) {
-    std::string list(skip); size_t p0 = 0;
-    while (p0 <= list.size()) {
-      const size_t p1 = list.find(',', p0);
-      const std::string pat = list.substr(p0, p1 == std::string::npos ? std::string::npos : p1 - p0);
-      if (!pat.empty() && op.name.find(pat) != std::string::npos) return;
-      if (p1 == std::string::npos) break;
-      p0 = p1 + 1;
-    }
-  }
   switch (op.kind) {
     case OP_STEM: {
       StemArgs a = op.stem; a.B = batch; a.in = in;
@@ -62,15 +49,12 @@ void launch_op(const Session& s, const Op& op, int batch, hipStream_t st, const 
     }
     case OP_PW: { PwArgs a = op.pw; a.M = batch * a.HW; launch_pw(a, st); break; }
     case OP_DW: { DwArgs a = op.dw; a.B = batch; launch_dw(a, st); break; }
-    case OP_SE: { SeArgs a = op.se; a.B = batch; launch_se(a, st); break; }
     case OP_POOL: { PoolArgs a = op.pool; a.B = batch; launch_pool(a, st); break; }
     case OP_PWG: { PwgArgs a = op.pwg; a.B = batch; launch_pwg(a, st); break; }
     case OP_MBF: { MbfArgs a = op.mbf; a.B = batch; launch_mbf(a, st); break; }
-    case OP_HEAD: { HeadArgs a = op.head; a.B = batch; launch_head(a, st); break; }
     case OP_SEP: {
       SepArgs a = op.sep; a.B = batch;
       if (a.direct) launch_tower(a, st);
-      else if (a.stream) { a.stream_blocks = std::max(1, std::min(a.total_tiles, (256 + batch - 1) / batch)); launch_sep_stream(a, st); }
       else launch_sep(a, st);
       break;
     }
@@ -154,6 +138,8 @@ int hep_create_from_memory(const void* pack, size_t pack_bytes, int phi, int siz
   std::unique_ptr<hep_handle> h(new hep_handle);
   Session& s = h->s;
   if (!make_arch(phi, &s.arch)) return fail(HEP_ERR_UNSUPPORTED, "phi must be in 0..7 (phi 8 needs a P8 level)");
+  Pack pk; std::string err;                       // host-only: a malformed pack is reported before any device is touched
+  if (!pk.parse(pack, pack_bytes, &err)) return fail(HEP_ERR_PACK, err);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
     return fail(HEP_ERR_DEVICE, "no HIP device visible: libhep has no CPU fallback");
@@ -170,8 +156,6 @@ int hep_create_from_memory(const void* pack, size_t pack_bytes, int phi, int siz
     s.lane_batch = (max_batch + lanes - 1) / lanes;
     s.lanes = (max_batch + s.lane_batch - 1) / s.lane_batch;
   }
-  Pack pk; std::string err;
-  if (!pk.parse(pack, pack_bytes, &err)) return fail(HEP_ERR_PACK, err);
   int rc = build_session(&s, pk, &err);
   if (rc != 0) return fail(rc, err);
   *out = h.release();
@@ -291,6 +275,23 @@ int hep_preprocess_u8_device(hep_handle* h, const uint8_t* rgb_hwc, int batch, i
   return 0;
 }
 
+// ---- decode / filter ----
+// The *_locked helpers expect s.mu to be held; the device entry points take it around the launch, the host
+// entry points around staging + launch + copy-back + synchronise, so that a concurrent call on the same handle
+// (the C# frame callbacks re-enter from WebRTC worker threads) can never see another caller's staged tensors.
+// Host inputs are staged in buffers of their own (d_stage), never in the forward's output buffers.
+static int decode_locked(Session& s, const float* regression, const float* translation_raw, const float* camera, int batch,
+                         float* boxes, float* translation, hipStream_t st) {
+  DecodeArgs a;
+  a.regression = regression ? regression : s.d_out[0];         // NULL = the handle's own last outputs
+  a.translation_raw = translation_raw ? translation_raw : s.d_out[3];
+  a.camera = camera; a.anchors = s.d_anchors; a.t_anchors = s.d_tanchors; a.boxes = boxes; a.translation = translation;
+  a.B = batch; a.N = s.num_anchors; a.clip_max = (float)(s.size - 1);
+  launch_decode(a, st);
+  HIPRET(hipGetLastError());
+  return 0;
+}
+
 int hep_decode_device(hep_handle* h, const float* regression, const float* translation_raw, const float* camera, int batch,
                       float* boxes, float* translation, void* stream) {
   if (!h || !camera || !boxes || !translation) return fail(HEP_ERR_INVALID, "bad argument");
@@ -298,14 +299,7 @@ int hep_decode_device(hep_handle* h, const float* regression, const float* trans
   if (batch < 1 || batch > s.max_batch) return fail(HEP_ERR_UNSUPPORTED, "batch outside 1..max_batch");
   std::lock_guard<std::mutex> lk(s.mu);
   HIPRET(hipSetDevice(s.device));
-  DecodeArgs a;
-  a.regression = regression ? regression : s.d_out[0];         // NULL = the handle's own last outputs
-  a.translation_raw = translation_raw ? translation_raw : s.d_out[3];
-  a.camera = camera; a.anchors = s.d_anchors; a.t_anchors = s.d_tanchors; a.boxes = boxes; a.translation = translation;
-  a.B = batch; a.N = s.num_anchors; a.clip_max = (float)(s.size - 1);
-  launch_decode(a, (hipStream_t)stream);
-  HIPRET(hipGetLastError());
-  return 0;
+  return decode_locked(s, regression, translation_raw, camera, batch, boxes, translation, (hipStream_t)stream);
 }
 
 static int ensure_post(Session& s) {
@@ -319,27 +313,53 @@ static int ensure_post(Session& s) {
   }
   return 0;
 }
+// staging buffer i (0 regression .. 4 hand, same widths as the outputs) for host-side inputs
+static int ensure_stage(Session& s, int i) {
+  if (!s.d_stage[i]) HIPRET(hipMalloc((void**)&s.d_stage[i], (size_t)s.max_batch * s.num_anchors * kOutK[i] * 4));
+  return 0;
+}
 
 int hep_decode(hep_handle* h, const float* regression, const float* translation_raw, const float* camera, int batch,
                float* boxes, float* translation) {
   if (!h || !camera || !boxes || !translation) return fail(HEP_ERR_INVALID, "bad argument");
   Session& s = h->s;
   if (batch < 1 || batch > s.max_batch) return fail(HEP_ERR_UNSUPPORTED, "batch outside 1..max_batch");
-  {
-    std::lock_guard<std::mutex> lk(s.mu);
-    HIPRET(hipSetDevice(s.device));
-    if (int rc = ensure_post(s)) return rc;
-    const size_t n = (size_t)batch * s.num_anchors;
-    // host inputs are staged into the handle's own output buffers (they hold the same tensors)
-    if (regression) HIPRET(hipMemcpyAsync(s.d_out[0], regression, n * 16, hipMemcpyHostToDevice, s.stream));
-    if (translation_raw) HIPRET(hipMemcpyAsync(s.d_out[3], translation_raw, n * 12, hipMemcpyHostToDevice, s.stream));
-    HIPRET(hipMemcpyAsync(s.d_cam, camera, (size_t)batch * 24, hipMemcpyHostToDevice, s.stream));
-  }
-  if (int rc = hep_decode_device(h, nullptr, nullptr, s.d_cam, batch, s.d_boxes, s.d_trans, s.stream)) return rc;
+  std::lock_guard<std::mutex> lk(s.mu);
+  HIPRET(hipSetDevice(s.device));
+  if (int rc = ensure_post(s)) return rc;
   const size_t n = (size_t)batch * s.num_anchors;
+  const float *dreg = nullptr, *dtrn = nullptr;
+  if (regression) {
+    if (int rc = ensure_stage(s, 0)) return rc;
+    HIPRET(hipMemcpyAsync(s.d_stage[0], regression, n * 16, hipMemcpyHostToDevice, s.stream)); dreg = s.d_stage[0];
+  }
+  if (translation_raw) {
+    if (int rc = ensure_stage(s, 3)) return rc;
+    HIPRET(hipMemcpyAsync(s.d_stage[3], translation_raw, n * 12, hipMemcpyHostToDevice, s.stream)); dtrn = s.d_stage[3];
+  }
+  HIPRET(hipMemcpyAsync(s.d_cam, camera, (size_t)batch * 24, hipMemcpyHostToDevice, s.stream));
+  if (int rc = decode_locked(s, dreg, dtrn, s.d_cam, batch, s.d_boxes, s.d_trans, s.stream)) return rc;
   HIPRET(hipMemcpyAsync(boxes, s.d_boxes, n * 16, hipMemcpyDeviceToHost, s.stream));
   HIPRET(hipMemcpyAsync(translation, s.d_trans, n * 12, hipMemcpyDeviceToHost, s.stream));
   HIPRET(hipStreamSynchronize(s.stream));
+  return 0;
+}
+
+static int filter_locked(Session& s, const float* boxes, const float* classification, const float* rotation,
+                         const float* translation, const float* hand, int batch, float score_threshold, float nms_threshold,
+                         int max_detections, float* det_boxes, float* det_scores, int32_t* det_labels, float* det_rotation,
+                         float* det_translation, float* det_hand, int32_t* det_index, int32_t* det_count, hipStream_t st) {
+  if (int rc = ensure_post(s)) return rc;
+  FilterArgs a;
+  a.boxes = boxes; a.scores = classification ? classification : s.d_out[1];
+  a.rotation = rotation ? rotation : s.d_out[2]; a.translation = translation ? translation : s.d_trans;
+  a.hand = hand ? hand : s.d_out[4];
+  a.B = batch; a.N = s.num_anchors; a.max_det = max_detections; a.score_thr = score_threshold; a.nms_thr = nms_threshold;
+  a.keys = s.d_keys; a.npow2 = s.npow2;
+  a.det_boxes = det_boxes; a.det_scores = det_scores; a.det_labels = det_labels; a.det_rotation = det_rotation;
+  a.det_translation = det_translation; a.det_hand = det_hand; a.det_index = det_index; a.det_count = det_count;
+  launch_filter(a, st);
+  HIPRET(hipGetLastError());
   return 0;
 }
 
@@ -353,18 +373,8 @@ int hep_filter_device(hep_handle* h, const float* boxes, const float* classifica
   if (max_detections < 1 || max_detections > 256) return fail(HEP_ERR_UNSUPPORTED, "max_detections must be in 1..256");
   std::lock_guard<std::mutex> lk(s.mu);
   HIPRET(hipSetDevice(s.device));
-  if (int rc = ensure_post(s)) return rc;
-  FilterArgs a;
-  a.boxes = boxes; a.scores = classification ? classification : s.d_out[1];
-  a.rotation = rotation ? rotation : s.d_out[2]; a.translation = translation ? translation : s.d_trans;
-  a.hand = hand ? hand : s.d_out[4];
-  a.B = batch; a.N = s.num_anchors; a.max_det = max_detections; a.score_thr = score_threshold; a.nms_thr = nms_threshold;
-  a.keys = s.d_keys; a.npow2 = s.npow2;
-  a.det_boxes = det_boxes; a.det_scores = det_scores; a.det_labels = det_labels; a.det_rotation = det_rotation;
-  a.det_translation = det_translation; a.det_hand = det_hand; a.det_index = det_index; a.det_count = det_count;
-  launch_filter(a, (hipStream_t)stream);
-  HIPRET(hipGetLastError());
-  return 0;
+  return filter_locked(s, boxes, classification, rotation, translation, hand, batch, score_threshold, nms_threshold, max_detections,
+                       det_boxes, det_scores, det_labels, det_rotation, det_translation, det_hand, det_index, det_count, (hipStream_t)stream);
 }
 
 int hep_filter(hep_handle* h, const float* boxes, const float* classification, const float* rotation, const float* translation,
@@ -376,24 +386,23 @@ int hep_filter(hep_handle* h, const float* boxes, const float* classification, c
   if (batch < 1 || batch > s.max_batch) return fail(HEP_ERR_UNSUPPORTED, "batch outside 1..max_batch");
   if (max_detections < 1 || max_detections > 256) return fail(HEP_ERR_UNSUPPORTED, "max_detections must be in 1..256");
   const size_t n = (size_t)batch * s.num_anchors, M = (size_t)batch * max_detections;
-  float* d = nullptr;
-  {
-    std::lock_guard<std::mutex> lk(s.mu);
-    HIPRET(hipSetDevice(s.device));
-    if (int rc = ensure_post(s)) return rc;
-    const size_t need = (size_t)s.max_batch * 256 * (4 + 1 + 1 + 3 + 3 + 63 + 1) + s.max_batch;
-    if (!s.d_det) { HIPRET(hipMalloc((void**)&s.d_det, need * 4)); s.det_floats = need; }
-    d = s.d_det;
-    HIPRET(hipMemcpyAsync(s.d_boxes, boxes, n * 16, hipMemcpyHostToDevice, s.stream));
-    HIPRET(hipMemcpyAsync(s.d_out[1], classification, n * 4, hipMemcpyHostToDevice, s.stream));
-    HIPRET(hipMemcpyAsync(s.d_out[2], rotation, n * 12, hipMemcpyHostToDevice, s.stream));
-    HIPRET(hipMemcpyAsync(s.d_trans, translation, n * 12, hipMemcpyHostToDevice, s.stream));
-    HIPRET(hipMemcpyAsync(s.d_out[4], hand, n * 63 * 4, hipMemcpyHostToDevice, s.stream));
-  }
+  std::lock_guard<std::mutex> lk(s.mu);
+  HIPRET(hipSetDevice(s.device));
+  if (int rc = ensure_post(s)) return rc;
+  for (int i = 0; i < 5; i++) if (int rc = ensure_stage(s, i)) return rc;
+  const size_t need = (size_t)s.max_batch * 256 * (4 + 1 + 1 + 3 + 3 + 63 + 1) + s.max_batch;
+  if (!s.d_det) { HIPRET(hipMalloc((void**)&s.d_det, need * 4)); s.det_floats = need; }
+  float* d = s.d_det;
+  // staged inputs: boxes -> stage 0 (same width as regression), scores 1, rotation 2, translation 3, hand 4
+  HIPRET(hipMemcpyAsync(s.d_stage[0], boxes, n * 16, hipMemcpyHostToDevice, s.stream));
+  HIPRET(hipMemcpyAsync(s.d_stage[1], classification, n * 4, hipMemcpyHostToDevice, s.stream));
+  HIPRET(hipMemcpyAsync(s.d_stage[2], rotation, n * 12, hipMemcpyHostToDevice, s.stream));
+  HIPRET(hipMemcpyAsync(s.d_stage[3], translation, n * 12, hipMemcpyHostToDevice, s.stream));
+  HIPRET(hipMemcpyAsync(s.d_stage[4], hand, n * 63 * 4, hipMemcpyHostToDevice, s.stream));
   float* b_ = d; float* sc_ = b_ + M * 4; int32_t* lb_ = (int32_t*)(sc_ + M); float* ro_ = (float*)(lb_ + M);
   float* tr_ = ro_ + M * 3; float* hd_ = tr_ + M * 3; int32_t* ix_ = (int32_t*)(hd_ + M * 63); int32_t* ct_ = ix_ + M;
-  if (int rc = hep_filter_device(h, s.d_boxes, nullptr, nullptr, nullptr, nullptr, batch, score_threshold, nms_threshold,
-                                 max_detections, b_, sc_, lb_, ro_, tr_, hd_, ix_, ct_, s.stream)) return rc;
+  if (int rc = filter_locked(s, s.d_stage[0], s.d_stage[1], s.d_stage[2], s.d_stage[3], s.d_stage[4], batch, score_threshold, nms_threshold,
+                             max_detections, b_, sc_, lb_, ro_, tr_, hd_, ix_, ct_, s.stream)) return rc;
   if (det_boxes) HIPRET(hipMemcpyAsync(det_boxes, b_, M * 16, hipMemcpyDeviceToHost, s.stream));
   if (det_scores) HIPRET(hipMemcpyAsync(det_scores, sc_, M * 4, hipMemcpyDeviceToHost, s.stream));
   if (det_labels) HIPRET(hipMemcpyAsync(det_labels, lb_, M * 4, hipMemcpyDeviceToHost, s.stream));
@@ -420,6 +429,7 @@ int hep_debug_tensor(hep_handle* h, const char* name, int batch, float* out, siz
   Session& s = h->s;
   auto it = s.tensor_by_name.find(name);
   if (it == s.tensor_by_name.end()) return fail(HEP_ERR_INVALID, std::string("no stage tensor named '") + name + "'");
+  if (batch < 1 || batch > s.max_batch) return fail(HEP_ERR_UNSUPPORTED, "batch outside 1..max_batch");
   const TensorDesc& t = s.tensors[it->second];
   const size_t n = (size_t)batch * t.H * t.W * t.C;
   if (n > capacity) return fail(HEP_ERR_INVALID, "output buffer too small");
@@ -461,19 +471,25 @@ int hep_kernel_symbol(const hep_handle* h, int i, const char** symbol) {
     case OP_STEM: snprintf(tmp, sizeof tmp, "stem_kernel<%s>", t); break;
     case OP_PW: snprintf(tmp, sizeof tmp, "pw_gemm_kernel<%s, %d, %d, %d, %d>", t, o.pw.MT, o.pw.NT, o.pw.mode, o.pw.act == ACT_SWISH ? 1 : 0); break;
     case OP_DW: snprintf(tmp, sizeof tmp, "dw_kernel<%s, %d, %d, %d>", t, o.dw.k, o.dw.s, o.dw.TW); break;
-    case OP_SE: snprintf(tmp, sizeof tmp, "se_kernel"); break;
     case OP_POOL: snprintf(tmp, sizeof tmp, "pool_kernel<%s>", t); break;
     case OP_PWG: snprintf(tmp, sizeof tmp, "pw_group_kernel<%s>", t); break;
     case OP_MBF: snprintf(tmp, sizeof tmp, "mbf_kernel<%s, %d, %d>", t, o.mbf.k, o.mbf.s); break;
-    case OP_HEAD: snprintf(tmp, sizeof tmp, "head_kernel<%s>", t); break;
     default: if (o.sep.direct) snprintf(tmp, sizeof tmp, "tower_kernel<%s, %d, %s>", t, o.sep.C, o.sep.direct == 2 ? "true" : "false");
-             else if (o.sep.stream) snprintf(tmp, sizeof tmp, "sep_stream_kernel<%s>", t);
              else snprintf(tmp, sizeof tmp, "sep_kernel<%s, %d>", t, o.sep.chain ? 2 : (o.sep.nseg == 1 ? 0 : 1));
              break;
   }
   buf = tmp; *symbol = buf.c_str();
   return 0;
 }
+
+namespace {
+struct EventSet {     // events and streams of the profilers, released on every return path
+  std::vector<hipEvent_t> ev; std::vector<hipStream_t> st;
+  ~EventSet() { for (hipEvent_t e : ev) hipEventDestroy(e); for (hipStream_t x : st) hipStreamDestroy(x); }
+  int add_events(size_t n) { for (size_t i = 0; i < n; i++) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return -1; ev.push_back(e); } return 0; }
+  int add_streams(size_t n) { for (size_t i = 0; i < n; i++) { hipStream_t x; if (hipStreamCreateWithFlags(&x, hipStreamNonBlocking) != hipSuccess) return -1; st.push_back(x); } return 0; }
+};
+}  // namespace
 
 int hep_profile(hep_handle* h, int batch, int iters, float* total_ms_per_iter, float* per_kernel_ms) {
   if (!h || iters < 1) return fail(HEP_ERR_INVALID, "bad argument");
@@ -483,7 +499,9 @@ int hep_profile(hep_handle* h, int batch, int iters, float* total_ms_per_iter, f
   HIPRET(hipSetDevice(s.device));
   const size_t in_floats = (size_t)3 * s.size * s.size;
   if (!s.d_in) { HIPRET(hipMalloc((void**)&s.d_in, in_floats * s.max_batch * 4)); HIPRET(hipMemset(s.d_in, 0, in_floats * s.max_batch * 4)); }
-  hipEvent_t e0, e1; HIPRET(hipEventCreate(&e0)); HIPRET(hipEventCreate(&e1));
+  EventSet es;
+  if (es.add_events(2)) return fail(HEP_ERR_DEVICE, "hipEventCreate failed");
+  hipEvent_t e0 = es.ev[0], e1 = es.ev[1];
   std::string err;
   const int64_t S = s.size; const int64_t st[4] = {3 * S * S, S * S, S, 1};
   for (int w = 0; w < 3; w++) if (int rc = run_forward(&s, s.d_in, st, batch, s.stream, &err)) return fail(rc, err);
@@ -498,8 +516,8 @@ int hep_profile(hep_handle* h, int batch, int iters, float* total_ms_per_iter, f
     // so each duration is taken in its real context (cold caches, real predecessor), on the stream
     // the kernel runs on.  It includes the inter-kernel boundary, like a hipGraph replay does.
     const size_t n = s.ops.size();
-    std::vector<hipEvent_t> ev(n + 1);
-    for (auto& e : ev) HIPRET(hipEventCreate(&e));
+    if (es.add_events(n + 1)) return fail(HEP_ERR_DEVICE, "hipEventCreate failed");
+    hipEvent_t* ev = es.ev.data() + 2;
     std::vector<double> acc(n, 0.0);
     for (int i = 0; i < iters + 1; i++) {
       for (size_t k = 0; k < n; k++) {     // lane 0's launches (lane_batch frames each), one after the other
@@ -512,9 +530,7 @@ int hep_profile(hep_handle* h, int batch, int iters, float* total_ms_per_iter, f
       for (size_t k = 0; k < n; k++) { HIPRET(hipEventElapsedTime(&ms, ev[k], ev[k + 1])); acc[k] += ms; }
     }
     for (size_t k = 0; k < n; k++) per_kernel_ms[k] = (float)(acc[k] / iters);
-    for (auto& e : ev) hipEventDestroy(e);
   }
-  hipEventDestroy(e0); hipEventDestroy(e1);
   return 0;
 }
 
@@ -530,8 +546,9 @@ int hep_profile_concurrent(hep_handle* h, int batch, int iters, int nstreams, fl
   const int64_t S = s.size; const int64_t st[4] = {3 * S * S, S * S, S, 1};
   if (int rc = run_forward(&s, s.d_in, st, batch, s.stream, &err)) return fail(rc, err);
   HIPRET(hipStreamSynchronize(s.stream));
-  std::vector<hipStream_t> ss(nstreams);
-  for (auto& x : ss) HIPRET(hipStreamCreateWithFlags(&x, hipStreamNonBlocking));
+  EventSet es;
+  if (es.add_streams(nstreams)) return fail(HEP_ERR_DEVICE, "hipStreamCreate failed");
+  std::vector<hipStream_t>& ss = es.st;
   const size_t n = s.ops.size();
   for (size_t k = 0; k < n; k++) {
     // the same launch repeated on every stream at once (identical inputs, identical outputs): its
@@ -544,7 +561,6 @@ int hep_profile_concurrent(hep_handle* h, int batch, int iters, int nstreams, fl
       if (rep) per_kernel_ms[k] = (float)(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / (iters * nstreams));
     }
   }
-  for (auto& x : ss) hipStreamDestroy(x);
   return 0;
 }
 

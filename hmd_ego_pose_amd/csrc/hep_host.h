@@ -45,12 +45,11 @@ struct TensorDesc {
   void* ext_ptr = nullptr;
 };
 
-enum OpKind { OP_STEM, OP_PW, OP_DW, OP_SE, OP_POOL, OP_SEP, OP_MBF, OP_HEAD, OP_PWG };
+enum OpKind { OP_STEM, OP_PW, OP_DW, OP_POOL, OP_SEP, OP_MBF, OP_PWG };
 struct Op {
   OpKind kind; std::string name;
-  StemArgs stem; PwArgs pw; DwArgs dw; SeArgs se; PoolArgs pool; SepArgs sep; MbfArgs mbf; HeadArgs head; PwgArgs pwg;
+  StemArgs stem; PwArgs pw; DwArgs dw; PoolArgs pool; SepArgs sep; MbfArgs mbf; PwgArgs pwg;
   std::vector<SepSeg> segs;         // host copy (device copy uploaded at build)
-  std::vector<HeadSeg> hsegs;
   std::vector<int> reads, writes;   // tensor ids
   double act_bytes_per_image = 0, flops_per_image = 0, weight_bytes = 0;
 };
@@ -78,6 +77,7 @@ struct Session {
   float* d_boxes = nullptr; float* d_trans = nullptr; float* d_cam = nullptr;
   uint64_t* d_keys = nullptr; int npow2 = 0;
   float* d_det = nullptr; size_t det_floats = 0;   // staging for host-buffer filter
+  float* d_stage[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // host-side inputs of hep_decode / hep_filter (never the forward's outputs)
   hipStream_t stream = nullptr;     // handle's own stream (host API, capture, profiling)
   std::map<int, std::vector<hipGraphExec_t>> graphs;   // per batch size: one graph per lane
   std::mutex mu;

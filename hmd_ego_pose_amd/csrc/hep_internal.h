@@ -24,7 +24,12 @@ struct StemArgs {
 // ---- pointwise conv as GEMM: out[M,N] = act((A[M,K] (*se)) . W[N,K]^T + bias) (+res) ----
 struct PwArgs {
   const void* A; const void* W; const float* bias;
-  const float* se;     // [B,K] per-image input-channel scale (nullable)
+  // squeeze-excite on the input side (project convs; hpart == nullptr: none): the front kernel left
+  // hpart[b][row][sqp] = per-workgroup partial products of the reduce FC with its channel sums; the
+  // prologue of this kernel finishes hidden = swish(sum_rows * inv_hw + br) and the expand FC
+  // scale[k] = sigmoid(we[k,:] . hidden + be[k]) for the images its rows belong to (k_pw.hip)
+  const float* hpart; const float* se_br; const float* se_we /*[K][sqp]*/; const float* se_be;
+  int se_rows, sq, sqp, se_nimg; float inv_hw;
   const void* res;     // [M,N] residual (nullable)
   void* out;
   int M, K, N, tilesN; // tilesN = ceil(N/16); W holds tilesN*16 rows
@@ -41,17 +46,11 @@ struct PwgArgs { PwgSeg seg[PWG_MAX]; int nseg, B, bf16, strips_per_image; };
 // ---- depthwise kxk conv + folded BN + swish (+ per-block channel sums for SE) ----
 struct DwArgs {
   const void* in; const float* w /*[k*k][C]*/; const float* bias; void* out;
-  float* partial;      // [B][blocks_per_image][C] (nullable)
+  float* hpart;        // [B][blocks_per_image][sqp]: partial reduce-FC products of this block's channel sums (nullable)
+  const float* se_wr;  // [sq][C] squeeze-excite reduce weight
+  int sq, sqp;
   int B, H, W, C, Ho, Wo, k, s, pad_t, pad_l, act, bf16, TW, blocks_per_image;
   uint32_t cg_magic, sw_magic, c_magic;   // reciprocals for C/8, strips per row and C (filled in by launch_dw)
-};
-
-// ---- squeeze-excite FCs: mean -> reduce(+swish) -> expand(+sigmoid) ----
-struct SeArgs {
-  const float* partial; int nblk; float inv_hw;
-  const float* wr /*[sq][C]*/; const float* br; const float* we /*[sq][C] (transposed)*/; const float* be;
-  float* scale;        // [B][C]
-  int B, C, sq;
 };
 
 // ---- fused MBConv front: expand 1x1 (+BN,swish) -> depthwise kxk (+BN,swish) -> SE partial sums ----
@@ -62,11 +61,12 @@ struct MbfArgs {
   const float* wdw;    // [k*k][Cexp], BN1 folded
   const float* bdw;    // [Cexp]
   void* out;           // [B,Ho,Wo,Cexp]
-  float* partial;      // [B][tiles][Cexp]
+  float* hpart;        // [B][tiles*chunks][sqp]: this workgroup's partial reduce-FC products (one row per workgroup)
+  const float* se_wr;  // [sq][Cexp] squeeze-excite reduce weight
+  int sq, sqp;
   int B, H, W, Cin, Cexp, Ho, Wo, k, s, pad_t, pad_l, has_expand, bf16;
   int CC;              // expanded channels per workgroup (8 * power of two)
   size_t off_e, off_we, off_w, lds_bytes;
-  int dbg_skip;        // bit mask of phases to skip (HEP_MBF_SKIP, timing experiments only)
 };
 
 // ---- 3x3 s2 max-pool, TF-SAME with ZERO padding (utils_extra.py:72-86) ----
@@ -95,29 +95,8 @@ struct SepArgs {
   SepSeg seg0;                               // the only segment of a single-segment launch (kernel argument)
   int nseg; int B; int total_tiles; int bf16; int C;
   int chain;                                 // segments are a dependency chain run by one workgroup per image
-  int stream, stream_blocks;                 // streaming kernel (k_sepstream.hip): workgroups per image, each a run of tiles
   int direct;                                // k_tower.hip (wave-per-patch, no LDS staging): 1 = map layer, 2 = headers
   size_t off_atile, off_wdw, off_bias, lds_bytes;   // LDS layout (k_sep.hip: sep_lds_layout)
-  int dbg_skip;                              // HEP_SEP_SKIP phase mask (timing experiments only)
-};
-
-// ---- fused heads: D tower layers + header(s) of one (net, level) per workgroup (k_head.hip) ----
-#define HEAD_MAX_DEPTH 5
-struct HeadOut {
-  const float* wdw; const void* wpw; const float* bias;   // header SeparableConv: [9][C], [ceil16(N)][C], [ceil16(N)]
-  float* out;                                             // [B, N_anchors, K] fp32
-  int N, act, col_kin, col_kout, col_off;                 // column n -> (n/kin)*kout + n%kin + off
-  int64_t out_bstride, out_rowstride;                     // floats per image, per anchor cell (9*K)
-};
-struct HeadSeg {
-  const void* feat; int h, w, tiles_x, tile_begin; int64_t out_cell0;     // level map, tiles, first anchor cell of the level
-  const float* wdw[HEAD_MAX_DEPTH]; const void* wpw[HEAD_MAX_DEPTH]; const float* bias[HEAD_MAX_DEPTH];   // tower (per-level BN folded)
-  int nheaders; HeadOut hdr[2];
-};
-struct HeadArgs {
-  const HeadSeg* segs; const int* tile_seg;
-  int nseg, B, total_tiles, bf16, C, depth, ts, chunk;    // ts: tile side; chunk: header columns per pass
-  size_t off_buf1, off_atile, off_wdw, off_bias, lds_bytes;
 };
 
 // ---- decode: boxes + translation from raw heads (loss.py:12-51) ----
@@ -147,25 +126,18 @@ void launch_stem(const StemArgs&, hipStream_t);
 void launch_pw(const PwArgs&, hipStream_t);
 void launch_pwg(const PwgArgs&, hipStream_t);
 void launch_dw(const DwArgs&, hipStream_t);
-void launch_se(const SeArgs&, hipStream_t);
 void launch_pool(const PoolArgs&, hipStream_t);
 void launch_mbf(const MbfArgs&, hipStream_t);
-#define MBF_SUM_ROWS 4            // waves of an mbf workgroup that run the depthwise phase (CC <= 64): partial-sum rows per tile
 size_t mbf_lds_layout(int Cin, int CC, int k, int s, int bf16, int has_expand, int max_inside, MbfArgs* a);
 int mbf_max_inside(int H, int W, int k, int s, int pad_t, int pad_l);
 int mbf_prepare(void);
 void launch_sep(const SepArgs&, hipStream_t);
-void launch_sep_stream(const SepArgs&, hipStream_t);
-int sep_stream_prepare(void);
 void launch_tower(const SepArgs&, hipStream_t);
 #define TOWER_BIAS_MAX 384       // bias floats staged per segment: >= 16 * n-tiles of any segment (24 map tiles, 12 per header chunk)
 #define TOWER_HDR_TILES 12       // n-tiles (16 columns) per header segment; wider headers are split into segments
 int tower_prepare(void);         // raises the dynamic-LDS limit of the tower kernels (call once per device)
 int tower_supports(int C);       // BiFPN widths k_tower.hip is instantiated for
 int tower_map_tiles(int C);      // n-tiles (even) of a map layer: its weight rows are permuted, see k_tower.hip
-void launch_head(const HeadArgs&, hipStream_t);
-void head_lds_layout(int C, int depth, int ts, int bf16, int chunk, HeadArgs* a);
-int head_prepare(void);
 void launch_decode(const DecodeArgs&, hipStream_t);
 void launch_export(const ExportArgs&, hipStream_t);
 void launch_preprocess(const PreprocArgs&, hipStream_t);

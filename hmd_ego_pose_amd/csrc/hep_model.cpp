@@ -121,10 +121,13 @@ bool Pack::parse(const void* blob, size_t n, std::string* err) {
     std::string name((const char*)p + q, nl); q += nl;
     int nd = p[q]; q += 1;
     if (nd > 8 || q + 4 * nd + 16 > n) return fail("truncated table");
-    PackTensor t; size_t cnt = 1;
-    for (int d = 0; d < nd; d++) { uint32_t v; memcpy(&v, p + q, 4); q += 4; t.dims.push_back(v); cnt *= v; }
+    PackTensor t; size_t cnt = 1; bool big = false;
+    for (int d = 0; d < nd; d++) {
+      uint32_t v; memcpy(&v, p + q, 4); q += 4; t.dims.push_back(v);
+      if (v != 0 && cnt > (n / 4) / v) big = true; else cnt *= v;      // checked product: a tensor cannot hold more floats than the file
+    }
     uint64_t off, nb; memcpy(&off, p + q, 8); memcpy(&nb, p + q + 8, 8); q += 16;
-    if (nb != cnt * 4 || off + nb > n || (off & 3)) return fail("tensor out of bounds");
+    if (big || nb != (uint64_t)cnt * 4 || off > n || nb > n - off || (off & 3) || off < 12) return fail("tensor out of bounds");
     t.data = (const float*)(p + off); t.count = cnt;
     tensors[name] = t;
   }
@@ -192,10 +195,9 @@ static bool fold_bn(const Pack& pk, const std::string& p, int c, BnFold* out, st
 // Because Op structs are stored by value in a vector that grows, pointer patching is done by
 // index after the plan is complete: each Op records symbolic references here.
 struct Ref { int op; int field; int seg; int idx; size_t woff; int tensor; };
-enum { F_STEM_W, F_STEM_B, F_STEM_OUT, F_PW_A, F_PW_W, F_PW_B, F_PW_SE, F_PW_RES, F_PW_OUT, F_DW_IN, F_DW_W, F_DW_B,
-       F_DW_OUT, F_DW_PART, F_MBF_IN, F_MBF_WE, F_MBF_BE, F_MBF_WDW, F_MBF_BDW, F_MBF_OUT, F_MBF_PART, F_SE_PART, F_SE_WR, F_SE_BR, F_SE_WE, F_SE_BE, F_SE_SCALE, F_POOL_IN, F_POOL_OUT, F_PWG_A, F_PWG_W, F_PWG_B, F_PWG_OUT,
-       F_SEG_SRC, F_SEG_WDW, F_SEG_WPW, F_SEG_BIAS, F_SEG_OUT,
-       F_HSEG_FEAT, F_HSEG_WDW, F_HSEG_WPW, F_HSEG_BIAS, F_HOUT_WDW, F_HOUT_WPW, F_HOUT_BIAS, F_HOUT_OUT };
+enum { F_STEM_W, F_STEM_B, F_STEM_OUT, F_PW_A, F_PW_W, F_PW_B, F_PW_RES, F_PW_OUT, F_DW_IN, F_DW_W, F_DW_B,
+       F_DW_OUT, F_DW_PART, F_DW_WR, F_MBF_IN, F_MBF_WE, F_MBF_BE, F_MBF_WDW, F_MBF_BDW, F_MBF_OUT, F_MBF_PART, F_MBF_WR, F_PW_HPART, F_PW_SEBR, F_PW_SEWE, F_PW_SEBE, F_POOL_IN, F_POOL_OUT, F_PWG_A, F_PWG_W, F_PWG_B, F_PWG_OUT,
+       F_SEG_SRC, F_SEG_WDW, F_SEG_WPW, F_SEG_BIAS, F_SEG_OUT };
 
 struct Planner {
   Session* s; const Pack& pk; std::string* err; WBuilder wb; bool ok = true;
@@ -222,7 +224,7 @@ struct Planner {
   }
   int new_op(OpKind k, const std::string& name) {
     Op o; memset(&o.stem, 0, sizeof o.stem); memset(&o.pw, 0, sizeof o.pw); memset(&o.dw, 0, sizeof o.dw);
-    memset(&o.se, 0, sizeof o.se); memset(&o.pool, 0, sizeof o.pool); memset(&o.sep, 0, sizeof o.sep); memset(&o.mbf, 0, sizeof o.mbf); memset(&o.head, 0, sizeof o.head); memset(&o.pwg, 0, sizeof o.pwg);
+    memset(&o.pool, 0, sizeof o.pool); memset(&o.sep, 0, sizeof o.sep); memset(&o.mbf, 0, sizeof o.mbf); memset(&o.pwg, 0, sizeof o.pwg);
     o.kind = k; o.name = name;
     s->ops.push_back(o);
     return (int)s->ops.size() - 1;
@@ -230,8 +232,10 @@ struct Planner {
   double es() const { return (double)s->esize(); }
 
   // ---- pointwise conv (weights [N][K] as in the state_dict; optional conv bias; optional BN) ----
+  // squeeze-excite of a project conv: the front kernel's partial reduce-FC rows + the rest of the two FCs
+  struct SeSpec { int hpart_t = -1, rows = 0, sq = 0, sqp = 0; float inv_hw = 0.f; size_t br = 0, we = 0, be = 0; };
   int add_pw(const std::string& name, int in_t, int HW, int K, int N, const std::string& wkey, const std::string& bkey,
-             const std::string& bnkey, int act, int se_t, int res_t, const std::string& out_name, int H, int W) {
+             const std::string& bnkey, int act, const SeSpec* se, int res_t, const std::string& out_name, int H, int W) {
     const PackTensor* w = get(wkey, {N, K, 1, 1});
     const PackTensor* cb = bkey.empty() ? nullptr : get(bkey, {N});
     BnFold bn;
@@ -274,11 +278,22 @@ struct Planner {
     }
     wref(op, F_PW_W, wb.put_typed(wf)); wref(op, F_PW_B, wb.put_f32(bf));
     tref(op, F_PW_A, in_t, false); tref(op, F_PW_OUT, out_t, true);
-    if (se_t >= 0) tref(op, F_PW_SE, se_t, false);
     if (res_t >= 0) tref(op, F_PW_RES, res_t, false);
     o.act_bytes_per_image = ((double)HW * K + (double)HW * N * (res_t >= 0 ? 2 : 1)) * es();
     o.weight_bytes = (double)N * K * es();
     o.flops_per_image = 2.0 * HW * K * N;
+    if (se) {
+      tref(op, F_PW_HPART, se->hpart_t, false);
+      wref(op, F_PW_SEBR, se->br); wref(op, F_PW_SEWE, se->we); wref(op, F_PW_SEBE, se->be);
+      o.pw.se_rows = se->rows; o.pw.sq = se->sq; o.pw.sqp = se->sqp; o.pw.inv_hw = se->inv_hw;
+      // images a workgroup's rows can belong to (its scale table in LDS holds that many): rows per workgroup
+      // and HW are multiples of 16 and workgroups start at multiples of their row count
+      const int rows_wg = o.pw.mode == 0 ? 64 * o.pw.MT : 16 * o.pw.MT;
+      o.pw.se_nimg = HW % rows_wg == 0 ? 1 : (rows_wg + HW - 1) / HW + 1;
+      o.act_bytes_per_image += ((double)se->rows * se->sqp + se->sq) * 4;
+      o.weight_bytes += ((double)K * se->sq + K + se->sq) * 4;
+      o.flops_per_image += 2.0 * K * se->sq;
+    }
     return out_t;
   }
 
@@ -350,19 +365,36 @@ struct Planner {
     if (want && !(mode && !strcmp(mode, "none")))
       for (int cand : {64, 32, 16})
         if (mbf_lds_layout(b.cin, std::min(cand, b.expand ? cand : b.cexp), b.k, b.stride, s->dtype, b.expand, max_in, nullptr) <= 159 * 1024) { CC = cand; break; }
+    // squeeze-excite weights: reduce FC [sq][Cexp] for the front kernel; bias, expand FC [Cexp][sqp] (rows
+    // padded to a multiple of 4 with zeros) and its bias for the project GEMM's prologue
+    const PackTensor *wr = get(p + "._se_reduce.conv.weight", {b.se, b.cexp, 1, 1}), *br = get(p + "._se_reduce.conv.bias", {b.se}),
+                     *we = get(p + "._se_expand.conv.weight", {b.cexp, b.se, 1, 1}), *be = get(p + "._se_expand.conv.bias", {b.cexp});
+    if (!ok) return -1;
+    const int sqp = (b.se + 3) & ~3;
+    if (sqp > 256) { *err = "squeeze-excite width above 256 is not supported"; ok = false; return -1; }
+    const size_t wr_off = wb.put_f32(std::vector<float>(wr->data, wr->data + wr->count));
+    SeSpec se; se.sq = b.se; se.sqp = sqp; se.inv_hw = 1.0f / (float)(Ho * Wo);
+    se.br = wb.put_f32(std::vector<float>(br->data, br->data + br->count));
+    {
+      std::vector<float> wep((size_t)b.cexp * sqp, 0.f);
+      for (int c = 0; c < b.cexp; c++) for (int j = 0; j < b.se; j++) wep[(size_t)c * sqp + j] = we->data[(size_t)c * b.se + j];
+      se.we = wb.put_f32(wep);
+    }
+    se.be = wb.put_f32(std::vector<float>(be->data, be->data + be->count));
     int part_t, nblk;
     if (CC) {
       if (!b.expand) CC = std::min(CC, b.cexp);
-      nblk = ((Ho + 7) / 8) * ((Wo + 7) / 8) * MBF_SUM_ROWS;
-      snprintf(nm, sizeof nm, "b%d.se_partial", i);
-      part_t = tensor(nm, 1, nblk, b.cexp, true);
+      nblk = ((Ho + 7) / 8) * ((Wo + 7) / 8) * ((b.cexp + CC - 1) / CC);      // one row per workgroup
+      snprintf(nm, sizeof nm, "b%d.se_hpart", i);
+      part_t = tensor(nm, 1, nblk, sqp, true);
       snprintf(nm, sizeof nm, "b%d.front", i);
       const int op = new_op(OP_MBF, nm);
       Op& o = s->ops[op];
       MbfArgs& m = o.mbf; memset(&m, 0, sizeof m);
       m.H = Hin; m.W = Win; m.Cin = b.cin; m.Cexp = b.cexp; m.Ho = Ho; m.Wo = Wo; m.k = b.k; m.s = b.stride;
-      m.pad_t = pt; m.pad_l = pl; m.has_expand = b.expand; m.bf16 = s->dtype; m.CC = CC;
+      m.pad_t = pt; m.pad_l = pl; m.has_expand = b.expand; m.bf16 = s->dtype; m.CC = CC; m.sq = b.se; m.sqp = sqp;
       mbf_lds_layout(b.cin, CC, b.k, b.stride, s->dtype, b.expand, max_in, &m);
+      wref(op, F_MBF_WR, wr_off);
       if (b.expand) {
         const PackTensor* w = get(p + "._expand_conv.conv.weight", {b.cexp, b.cin, 1, 1});
         BnFold bn0; if (!fold_bn(pk, p + "._bn0", b.cexp, &bn0, err)) ok = false;
@@ -380,7 +412,7 @@ struct Planner {
     } else {
       if (b.expand) {
         snprintf(nm, sizeof nm, "b%d.expand", i);
-        x = add_pw(nm, x, Hin * Win, b.cin, b.cexp, p + "._expand_conv.conv.weight", "", p + "._bn0", ACT_SWISH, -1, -1,
+        x = add_pw(nm, x, Hin * Win, b.cin, b.cexp, p + "._expand_conv.conv.weight", "", p + "._bn0", ACT_SWISH, nullptr, -1,
                    std::string(nm), Hin, Win);
         if (!ok) return -1;
       }
@@ -393,16 +425,17 @@ struct Planner {
       const bool lds_dw = dl ? atoi(dl) != 0 : (Hin <= 8 || (b.k == 5 && Hin <= 64));
       const int ccl = std::min(64, b.cexp);
       if (lds_dw && mbf_lds_layout(b.cexp, ccl, b.k, b.stride, s->dtype, 0, max_in, nullptr) <= 159 * 1024) {
-        nblk = ((Ho + 7) / 8) * ((Wo + 7) / 8) * MBF_SUM_ROWS;
-        snprintf(nm, sizeof nm, "b%d.se_partial", i);
-        part_t = tensor(nm, 1, nblk, b.cexp, true);
+        nblk = ((Ho + 7) / 8) * ((Wo + 7) / 8) * ((b.cexp + ccl - 1) / ccl);
+        snprintf(nm, sizeof nm, "b%d.se_hpart", i);
+        part_t = tensor(nm, 1, nblk, sqp, true);
         snprintf(nm, sizeof nm, "b%d.dw", i);
         const int op = new_op(OP_MBF, nm);
         Op& o = s->ops[op];
         MbfArgs& m = o.mbf; memset(&m, 0, sizeof m);
         m.H = Hin; m.W = Win; m.Cin = b.cexp; m.Cexp = b.cexp; m.Ho = Ho; m.Wo = Wo; m.k = b.k; m.s = b.stride;
-        m.pad_t = pt; m.pad_l = pl; m.has_expand = 0; m.bf16 = s->dtype; m.CC = ccl;
+        m.pad_t = pt; m.pad_l = pl; m.has_expand = 0; m.bf16 = s->dtype; m.CC = ccl; m.sq = b.se; m.sqp = sqp;
         mbf_lds_layout(b.cexp, ccl, b.k, b.stride, s->dtype, 0, max_in, &m);
+        wref(op, F_MBF_WR, wr_off);
         wref(op, F_MBF_WDW, wb.put_f32(wdw)); wref(op, F_MBF_BDW, wb.put_f32(bn1.shift));
         tref(op, F_MBF_IN, x, false); tref(op, F_MBF_OUT, dw_t, true); tref(op, F_MBF_PART, part_t, true);
         o.act_bytes_per_image = ((double)Hin * Win + (double)Ho * Wo) * b.cexp * es();
@@ -413,46 +446,25 @@ struct Planner {
         // output, so 2 keeps their loads denser (measured 18.1 us against 19.8 us on 128x128 -> 64x64 x 96)
         const int TW = Wo >= 32 ? (b.stride == 2 ? 2 : 4) : (Wo >= 16 ? 2 : 1);
         nblk = dw_blocks_per_image(Ho, Wo, b.cexp, TW);
-        snprintf(nm, sizeof nm, "b%d.se_partial", i);
-        part_t = tensor(nm, 1, nblk, b.cexp, true);
+        snprintf(nm, sizeof nm, "b%d.se_hpart", i);
+        part_t = tensor(nm, 1, nblk, sqp, true);
         snprintf(nm, sizeof nm, "b%d.dw", i);
         const int op = new_op(OP_DW, nm);
         Op& o = s->ops[op];
         o.dw.H = Hin; o.dw.W = Win; o.dw.C = b.cexp; o.dw.Ho = Ho; o.dw.Wo = Wo; o.dw.k = b.k; o.dw.s = b.stride;
         o.dw.pad_t = pt; o.dw.pad_l = pl; o.dw.act = ACT_SWISH; o.dw.bf16 = s->dtype; o.dw.TW = TW; o.dw.blocks_per_image = nblk;
-        wref(op, F_DW_W, wb.put_f32(wdw)); wref(op, F_DW_B, wb.put_f32(bn1.shift));
+        o.dw.sq = b.se; o.dw.sqp = sqp;
+        wref(op, F_DW_W, wb.put_f32(wdw)); wref(op, F_DW_B, wb.put_f32(bn1.shift)); wref(op, F_DW_WR, wr_off);
         tref(op, F_DW_IN, x, false); tref(op, F_DW_OUT, dw_t, true); tref(op, F_DW_PART, part_t, true);
         o.act_bytes_per_image = ((double)Hin * Win + (double)Ho * Wo) * b.cexp * es();
         o.weight_bytes = (double)b.k * b.k * b.cexp * 4;
         o.flops_per_image = 2.0 * b.k * b.k * Ho * Wo * b.cexp;
       }
       }
-    const int bpi = nblk;
-    // squeeze-excite FCs
-    const PackTensor *wr = get(p + "._se_reduce.conv.weight", {b.se, b.cexp, 1, 1}), *br = get(p + "._se_reduce.conv.bias", {b.se}),
-                     *we = get(p + "._se_expand.conv.weight", {b.cexp, b.se, 1, 1}), *be = get(p + "._se_expand.conv.bias", {b.cexp});
-    if (!ok) return -1;
-    snprintf(nm, sizeof nm, "b%d.se_scale", i);
-    const int scale_t = tensor(nm, 1, 1, b.cexp, true);
-    {
-      snprintf(nm, sizeof nm, "b%d.se", i);
-      const int op = new_op(OP_SE, nm);
-      Op& o = s->ops[op];
-      o.se.nblk = bpi; o.se.inv_hw = 1.0f / (float)(Ho * Wo); o.se.C = b.cexp; o.se.sq = b.se;
-      wref(op, F_SE_WR, wb.put_f32(std::vector<float>(wr->data, wr->data + wr->count)));
-      wref(op, F_SE_BR, wb.put_f32(std::vector<float>(br->data, br->data + br->count)));
-      std::vector<float> wet((size_t)b.cexp * b.se);   // [sq][C]: the expand FC reads coalesced rows
-      for (int c = 0; c < b.cexp; c++) for (int j = 0; j < b.se; j++) wet[(size_t)j * b.cexp + c] = we->data[(size_t)c * b.se + j];
-      wref(op, F_SE_WE, wb.put_f32(wet));
-      wref(op, F_SE_BE, wb.put_f32(std::vector<float>(be->data, be->data + be->count)));
-      tref(op, F_SE_PART, part_t, false); tref(op, F_SE_SCALE, scale_t, true);
-      o.act_bytes_per_image = ((double)bpi * b.cexp + b.cexp) * 4;
-      o.weight_bytes = 2.0 * b.cexp * b.se * 4;
-      o.flops_per_image = 4.0 * b.cexp * b.se;
-    }
+    se.hpart_t = part_t; se.rows = nblk;
     // project + bn2 (+ residual), SE scale applied on the GEMM's input side
     snprintf(nm, sizeof nm, "b%d.project", i);
-    x = add_pw(nm, dw_t, Ho * Wo, b.cexp, b.cout, p + "._project_conv.conv.weight", "", p + "._bn2", ACT_NONE, scale_t,
+    x = add_pw(nm, dw_t, Ho * Wo, b.cexp, b.cout, p + "._project_conv.conv.weight", "", p + "._bn2", ACT_NONE, &se,
                b.skip ? inp : -1, std::string("block") + std::to_string(i), Ho, Wo);
     *H = Ho; *W = Wo;
     return x;
@@ -557,18 +569,9 @@ struct Planner {
     Op& o = s->ops[op];
     o.sep.nseg = (int)o.segs.size(); o.sep.total_tiles = tile_begin; o.sep.bf16 = s->dtype; o.sep.C = C;
     o.sep.chain = chain && o.segs.size() > 1;
-    {   // many independent single-source segments (head layers): the streaming kernel can pipeline runs of tiles
-      bool simple = o.segs.size() > 1 && !o.sep.chain && C <= 160;
-      for (const SepSeg& g : o.segs) simple = simple && g.nsrc == 1 && g.kind[0] == SRC_SAME && !g.pre_act && g.fw[0] == 1.f && g.ts == 8;
-      // measured on MI355X at bs16: 50 us per tower layer and 157 us for the headers against 46 / 112 us
-      // for one tile per workgroup (k_sep.hip mode 1) and 16 / 28 us for k_tower.hip, so the streaming
-      // kernel is opt-in (HEP_TOWER=0 HEP_STREAM=1)
-      const char* e = getenv("HEP_STREAM");
-      o.sep.stream = simple && e && atoi(e) != 0;
-    }
     o.sep.direct = direct;
     sep_lds_layout(C, s->dtype, ts_max, cols_f32, cols_map, &o.sep);
-    if (direct) { o.sep.stream = 0; o.sep.off_wdw = 0; o.sep.off_bias = (size_t)9 * C * 4; o.sep.lds_bytes = o.sep.off_bias + (size_t)tiles_n_max * 16 * 4; }
+    if (direct) { o.sep.off_wdw = 0; o.sep.off_bias = (size_t)9 * C * 4; o.sep.lds_bytes = o.sep.off_bias + (size_t)tiles_n_max * 16 * 4; }
     if (o.sep.lds_bytes > 160 * 1024) { *err = "BiFPN width too large for the fused separable-conv tile"; ok = false; return; }
     o.act_bytes_per_image = bytes; o.flops_per_image = flops; o.weight_bytes = wbytes;
   }
@@ -648,7 +651,7 @@ int build_session(Session* s, const Pack& pack, std::string* err) {
       } else {
         for (int i = 0; i < 6; i++)
           lat_out[i] = P.add_pw(tn + lat[i].nm, taps[lat[i].tap], lat[i].L * lat[i].L, A.tap_channels[lat[i].tap], Wf, p + lat[i].key + ".0.conv.weight",
-                                p + lat[i].key + ".0.conv.bias", p + lat[i].key + ".1", ACT_NONE, -1, -1, tn + lat[i].out, lat[i].L, lat[i].L);
+                                p + lat[i].key + ".0.conv.bias", p + lat[i].key + ".1", ACT_NONE, nullptr, -1, tn + lat[i].out, lat[i].L, lat[i].L);
       }
       in[0] = lat_out[0]; in[1] = lat_out[1]; in[2] = lat_out[2]; in2[1] = lat_out[3]; in2[2] = lat_out[4]; p6pre = lat_out[5];
       if (!P.ok) return HEP_ERR_PACK;
@@ -719,76 +722,8 @@ int build_session(Session* s, const Pack& pack, std::string* err) {
                             {3, "translation_net.initial_translation_xy", 2, 3, 0, 3, ACT_NONE},
                             {3, "translation_net.initial_translation_z", 1, 3, 2, 3, ACT_NONE},
                             {4, "hand_net.initial_hand_coords", 63, 63, 0, 4, ACT_NONE}};
-  // Two implementations: one sepconv launch per tower layer + one for the headers (k_sep.hip), or
-  // ONE launch for all five heads with towers + headers fused per (net, level, tile) and the
-  // intermediate maps in LDS (k_head.hip; needs the two tower maps to fit in LDS).
-  HeadArgs ha; memset(&ha, 0, sizeof ha);
-  ha.C = Wf; ha.depth = A.head_depth; ha.bf16 = s->dtype; ha.chunk = 96;
-  bool fused_heads = false;
-  for (int ts : {8, 4}) {
-    ha.ts = ts; head_lds_layout(Wf, A.head_depth, ts, s->dtype, ha.chunk, &ha);
-    if (ha.lds_bytes <= 159 * 1024 && A.head_depth <= HEAD_MAX_DEPTH) { fused_heads = true; break; }
-  }
-  // Measured on MI355X at bs16: the fused kernel (halo recompute, 1 workgroup per CU) takes 282 us
-  // against 240 us for D+1 per-layer launches of k_sep.hip and 75 us for those of k_tower.hip, so the
-  // per-layer path is the default; HEP_HEAD=fused selects the fused kernel (kept parity-tested).
-  { const char* e = getenv("HEP_HEAD"); if (!(e && !strcmp(e, "fused"))) fused_heads = false; }
-  if (fused_heads) {
-    const int op = P.new_op(OP_HEAD, "heads.fused");
-    double bytes = 0, flops = 0, wbytes = 0;
-    int tile_begin = 0;
-    for (int n = 0; n < 5; n++)
-      for (int l = 0; l < 5; l++) {
-        HeadSeg sg; memset(&sg, 0, sizeof sg);
-        const int hw = s->levels[l], si = n * 5 + l;
-        sg.h = hw; sg.w = hw; sg.tiles_x = (hw + ha.ts - 1) / ha.ts; sg.tile_begin = tile_begin; sg.out_cell0 = s->level_off[l] / 9;
-        tile_begin += sg.tiles_x * sg.tiles_x;
-        s->ops[op].hsegs.push_back(sg);
-        P.tref(op, F_HSEG_FEAT, feat[l], false, si);
-        bytes += (double)hw * hw * Wf * P.es();
-        for (int i = 0; i < A.head_depth; i++) {
-          const std::string key = std::string(nets[n]) + ".conv_list." + std::to_string(i);
-          const PackTensor* wd = P.get(key + ".depthwise_conv.conv.weight", {Wf, 1, 3, 3});
-          const PackTensor* wp = P.get(key + ".pointwise_conv.conv.weight", {Wf, Wf, 1, 1});
-          const PackTensor* bp = P.get(key + ".pointwise_conv.conv.bias", {Wf});
-          BnFold bn; if (!fold_bn(pack, std::string(nets[n]) + ".bn_list." + std::to_string(l) + "." + std::to_string(i), Wf, &bn, err)) P.ok = false;
-          if (!P.ok) return HEP_ERR_PACK;
-          std::vector<float> wdw((size_t)9 * Wf), wf((size_t)Wf * Wf), bf(Wf);
-          for (int c = 0; c < Wf; c++) for (int t = 0; t < 9; t++) wdw[(size_t)t * Wf + c] = wd->data[(size_t)c * 9 + t];
-          for (int o = 0; o < Wf; o++) {
-            for (int k = 0; k < Wf; k++) wf[(size_t)o * Wf + k] = wp->data[(size_t)o * Wf + k] * bn.scale[o];
-            bf[o] = bp->data[o] * bn.scale[o] + bn.shift[o];
-          }
-          P.wref(op, F_HSEG_WDW, P.wb.put_f32(wdw), si, i); P.wref(op, F_HSEG_WPW, P.wb.put_typed(wf), si, i);
-          P.wref(op, F_HSEG_BIAS, P.wb.put_f32(bf), si, i);
-          flops += 2.0 * hw * hw * Wf * (9 + Wf); wbytes += (double)Wf * Wf * P.es() + 10.0 * Wf * 4;
-        }
-        int nh = 0;
-        for (const Hd& h : hds) {
-          if (h.net != n) continue;
-          const int N = 9 * h.kin, rows = (N + 15) / 16 * 16;
-          const PackTensor* wd = P.get(std::string(h.key) + ".depthwise_conv.conv.weight", {Wf, 1, 3, 3});
-          const PackTensor* wp = P.get(std::string(h.key) + ".pointwise_conv.conv.weight", {N, Wf, 1, 1});
-          const PackTensor* bp = P.get(std::string(h.key) + ".pointwise_conv.conv.bias", {N});
-          if (!P.ok) return HEP_ERR_PACK;
-          std::vector<float> wdw((size_t)9 * Wf), wf((size_t)rows * Wf, 0.f), bf(rows, 0.f);
-          for (int c = 0; c < Wf; c++) for (int t = 0; t < 9; t++) wdw[(size_t)t * Wf + c] = wd->data[(size_t)c * 9 + t];
-          for (int o = 0; o < N; o++) { for (int k = 0; k < Wf; k++) wf[(size_t)o * Wf + k] = wp->data[(size_t)o * Wf + k]; bf[o] = bp->data[o]; }
-          HeadOut& ho = s->ops[op].hsegs[si].hdr[nh];
-          ho.N = N; ho.act = h.act; ho.col_kin = h.kin; ho.col_kout = h.kout; ho.col_off = h.off;
-          ho.out_bstride = (int64_t)s->num_anchors * h.kout; ho.out_rowstride = 9 * h.kout;
-          P.wref(op, F_HOUT_WDW, P.wb.put_f32(wdw), si, nh); P.wref(op, F_HOUT_WPW, P.wb.put_typed(wf), si, nh);
-          P.wref(op, F_HOUT_BIAS, P.wb.put_f32(bf), si, nh);
-          P.refs.push_back({op, F_HOUT_OUT, si, nh, 0, -(h.out + 2)});
-          bytes += (double)hw * hw * N * 4; flops += 2.0 * hw * hw * Wf * (9 + N); wbytes += (double)N * Wf * P.es() + 9.0 * Wf * 4;
-          nh++;
-        }
-        s->ops[op].hsegs[si].nheaders = nh;
-      }
-    Op& o = s->ops[op];
-    ha.nseg = 25; ha.total_tiles = tile_begin;
-    o.head = ha; o.act_bytes_per_image = bytes; o.flops_per_image = flops; o.weight_bytes = wbytes;
-  } else {
+  // one launch per tower layer (all five nets x five levels) + one for all headers (k_tower.hip)
+  {
     int cur[5][5];
     for (int n = 0; n < 5; n++) for (int l = 0; l < 5; l++) cur[n][l] = feat[l];
     for (int i = 0; i < A.head_depth; i++) {
@@ -820,7 +755,6 @@ int build_session(Session* s, const Pack& pack, std::string* err) {
       P.add_sep("heads.headers", specs);
       if (!P.ok) return HEP_ERR_PACK;
     }
-
   }
 
   // ---- arena layout: first-fit with liveness-based reuse ----
@@ -873,8 +807,6 @@ int build_session(Session* s, const Pack& pack, std::string* err) {
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { *err = std::string(#x) + ": " + hipGetErrorString(e_); return HEP_ERR_DEVICE; } } while (0)
   HIPCHK(hipSetDevice(s->device));
   if (mbf_prepare() != 0) { *err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for mbf_kernel"; return HEP_ERR_DEVICE; }
-  if (head_prepare() != 0) { *err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for head_kernel"; return HEP_ERR_DEVICE; }
-  if (sep_stream_prepare() != 0) { *err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for sep_stream_kernel"; return HEP_ERR_DEVICE; }
   if (tower_prepare() != 0) { *err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for tower_kernel"; return HEP_ERR_DEVICE; }
   if (sep_prepare() != 0) { *err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"; return HEP_ERR_DEVICE; }
   HIPCHK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
@@ -910,27 +842,26 @@ int build_session(Session* s, const Pack& pack, std::string* err) {
         case F_PW_A: o.pw.A = ptr; break;
         case F_PW_W: o.pw.W = ptr; break;
         case F_PW_B: o.pw.bias = (const float*)ptr; break;
-        case F_PW_SE: o.pw.se = (const float*)ptr; break;
+        case F_PW_HPART: o.pw.hpart = (const float*)ptr; break;
+        case F_PW_SEBR: o.pw.se_br = (const float*)ptr; break;
+        case F_PW_SEWE: o.pw.se_we = (const float*)ptr; break;
+        case F_PW_SEBE: o.pw.se_be = (const float*)ptr; break;
         case F_PW_RES: o.pw.res = ptr; break;
         case F_PW_OUT: o.pw.out = ptr; break;
         case F_DW_IN: o.dw.in = ptr; break;
         case F_DW_W: o.dw.w = (const float*)ptr; break;
         case F_DW_B: o.dw.bias = (const float*)ptr; break;
         case F_DW_OUT: o.dw.out = ptr; break;
-        case F_DW_PART: o.dw.partial = (float*)ptr; break;
+        case F_DW_PART: o.dw.hpart = (float*)ptr; break;
+        case F_DW_WR: o.dw.se_wr = (const float*)ptr; break;
         case F_MBF_IN: o.mbf.in = ptr; break;
         case F_MBF_WE: o.mbf.we = ptr; break;
         case F_MBF_BE: o.mbf.be = (const float*)ptr; break;
         case F_MBF_WDW: o.mbf.wdw = (const float*)ptr; break;
         case F_MBF_BDW: o.mbf.bdw = (const float*)ptr; break;
         case F_MBF_OUT: o.mbf.out = ptr; break;
-        case F_MBF_PART: o.mbf.partial = (float*)ptr; break;
-        case F_SE_PART: o.se.partial = (const float*)ptr; break;
-        case F_SE_WR: o.se.wr = (const float*)ptr; break;
-        case F_SE_BR: o.se.br = (const float*)ptr; break;
-        case F_SE_WE: o.se.we = (const float*)ptr; break;
-        case F_SE_BE: o.se.be = (const float*)ptr; break;
-        case F_SE_SCALE: o.se.scale = (float*)ptr; break;
+        case F_MBF_PART: o.mbf.hpart = (float*)ptr; break;
+        case F_MBF_WR: o.mbf.se_wr = (const float*)ptr; break;
         case F_POOL_IN: o.pool.in = ptr; break;
         case F_POOL_OUT: o.pool.out = ptr; break;
         case F_PWG_A: o.pwg.seg[r.seg].A = ptr; break;
@@ -942,14 +873,6 @@ int build_session(Session* s, const Pack& pack, std::string* err) {
         case F_SEG_WPW: o.segs[r.seg].wpw = ptr; break;
         case F_SEG_BIAS: o.segs[r.seg].bias = (const float*)ptr; break;
         case F_SEG_OUT: o.segs[r.seg].out = ptr; break;
-        case F_HSEG_FEAT: o.hsegs[r.seg].feat = ptr; break;
-        case F_HSEG_WDW: o.hsegs[r.seg].wdw[r.idx] = (const float*)ptr; break;
-        case F_HSEG_WPW: o.hsegs[r.seg].wpw[r.idx] = ptr; break;
-        case F_HSEG_BIAS: o.hsegs[r.seg].bias[r.idx] = (const float*)ptr; break;
-        case F_HOUT_WDW: o.hsegs[r.seg].hdr[r.idx].wdw = (const float*)ptr; break;
-        case F_HOUT_WPW: o.hsegs[r.seg].hdr[r.idx].wpw = ptr; break;
-        case F_HOUT_BIAS: o.hsegs[r.seg].hdr[r.idx].bias = (const float*)ptr; break;
-        case F_HOUT_OUT: o.hsegs[r.seg].hdr[r.idx].out = (float*)ptr; break;
       }
     }
     // segment tables to device
@@ -965,16 +888,6 @@ int build_session(Session* s, const Pack& pack, std::string* err) {
         HIPCHK(hipMemcpy(dt, tile_seg.data(), tile_seg.size() * sizeof(int), hipMemcpyHostToDevice));
         o.sep.tile_seg = dt;
         o.sep.seg0 = o.segs[0];
-      } else if (o.kind == OP_HEAD) {
-        HeadSeg* d; HIPCHK(hipMalloc((void**)&d, o.hsegs.size() * sizeof(HeadSeg)));
-        HIPCHK(hipMemcpy(d, o.hsegs.data(), o.hsegs.size() * sizeof(HeadSeg), hipMemcpyHostToDevice));
-        o.head.segs = d;
-        std::vector<int> tile_seg(o.head.total_tiles);
-        for (size_t si = 0; si < o.hsegs.size(); si++)
-          for (int t = 0; t < o.hsegs[si].tiles_x * o.hsegs[si].tiles_x; t++) tile_seg[o.hsegs[si].tile_begin + t] = (int)si;
-        int* dt; HIPCHK(hipMalloc((void**)&dt, tile_seg.size() * sizeof(int)));
-        HIPCHK(hipMemcpy(dt, tile_seg.data(), tile_seg.size() * sizeof(int), hipMemcpyHostToDevice));
-        o.head.tile_seg = dt;
       }
   }
 #undef HIPCHK

@@ -1,5 +1,5 @@
 // k_dw.hip - the HBM-bound side of the EfficientNet backbone on gfx950: stem conv, depthwise
-// kxk conv (+BN+swish, + squeeze-excite partial sums), the SE fully-connected pair and the
+// kxk conv (+BN+swish, + the squeeze-excite channel sums folded into partial reduce-FC products) and the
 // zero-padded 3x3/2 max-pool.  NHWC activations, 8 channels (16 B in bf16) per lane so every
 // wave-level access is a run of full 16-byte vectors along C.
 #include "hep_dev.h"
@@ -73,7 +73,8 @@ void launch_stem(const StemArgs& a, hipStream_t s) {
 // A lane owns 8 channels of a strip of TW output pixels along W: every input vector it loads
 // feeds up to K taps, and the K x K x 8 weights are loaded once per row of taps.
 // Squeeze-excite: each lane sums its post-swish outputs, the block reduces them through LDS in a
-// FIXED order and writes partial[b][block][c] - no atomics, so the result is bit-reproducible.
+// FIXED order and writes their partial reduce-FC products hpart[b][block][j] - no atomics, so the
+// result is bit-reproducible.
 // ------------------------------------------------------------------------------------------------
 // exact x / d for x * d < 2^32 with m = floor(2^32 / d) + 1 (two VALU instructions instead of ~30)
 __device__ __forceinline__ int fast_div(int x, uint32_t m) { return (int)__umulhi((uint32_t)x, m); }
@@ -156,9 +157,10 @@ __global__ __launch_bounds__(256) void dw_kernel(DwArgs a) {
     }
   }
 
-  if (a.partial) {   // deterministic per-block channel sums for the squeeze-excite mean
+  if (a.hpart) {   // squeeze-excite: deterministic per-block channel sums -> partial reduce-FC products
     // thread t owns channel group (first_item + t) % CG.  Two steps, both in a fixed order: G = 256 / C
     // helper groups each add every G-th contribution of a channel, then the G helpers are added up.
+    float* chs = dw_smem + (KS * KS + 1) * a.C + 256 * 9;          // [C] channel sums of this block
 #pragma unroll
     for (int c = 0; c < 8; c++) red[threadIdx.x][c] = sum[c];
     __syncthreads();
@@ -182,7 +184,21 @@ __global__ __launch_bounds__(256) void dw_kernel(DwArgs a) {
         int t = ocg - first_cg; if (t < 0) t += CG;
         for (; t < 256; t += CG) s_ += red[t][oc];
       }
-      a.partial[((int64_t)b * a.blocks_per_image + blockIdx.x) * a.C + oo] = s_;
+      chs[oo] = s_;
+    }
+    __syncthreads();
+    // the mean and the reduce FC are linear in these sums: hpart[b][block][j] = sum_c wr[j][c] * chs[c]; the
+    // project GEMM adds the blocks up and finishes the squeeze-excite in its prologue (k_pw.hip).  32 lanes
+    // per hidden unit, lane butterfly in a fixed order.
+    const int lp = threadIdx.x & 31;
+    float* hrow = a.hpart + ((int64_t)b * a.blocks_per_image + blockIdx.x) * a.sqp;
+    for (int j = threadIdx.x >> 5; j < ((a.sq + 7) & ~7); j += 8) {
+      float dot = 0.f;
+      if (j < a.sq)
+        for (int c = lp; c < C; c += 32) dot = fmaf(a.se_wr[(int64_t)j * C + c], chs[c], dot);
+#pragma unroll
+      for (int off = 1; off < 32; off <<= 1) dot += __shfl_xor(dot, off, 64);
+      if (lp == 0 && j < a.sq) hrow[j] = dot;
     }
   }
 }
@@ -194,7 +210,7 @@ int dw_blocks_per_image(int Ho, int Wo, int C, int TW) {
 
 template <bool BF16, int KS, int S>
 static void launch_dw_tw(const DwArgs& a, dim3 grid, hipStream_t s) {
-  const size_t lds = ((size_t)(KS * KS + 1) * a.C + 256 * 9) * sizeof(float);
+  const size_t lds = ((size_t)(KS * KS + 1) * a.C + 256 * 9 + a.C) * sizeof(float);
   switch (a.TW) {
     case 1: hipLaunchKernelGGL((dw_kernel<BF16, KS, S, 1>), grid, dim3(256), lds, s, a); break;
     case 2: hipLaunchKernelGGL((dw_kernel<BF16, KS, S, 2>), grid, dim3(256), lds, s, a); break;
@@ -215,115 +231,6 @@ void launch_dw(const DwArgs& a_, hipStream_t s) {
   a.c_magic = (uint32_t)(0x100000000ull / (uint32_t)a.C) + 1;
   dim3 grid(a.blocks_per_image, a.B);
   if (a.bf16) launch_dw_t<true>(a, grid, s); else launch_dw_t<false>(a, grid, s);
-}
-
-// ------------------------------------------------------------------------------------------------
-// squeeze-excite: mean over HW (from the per-block partial sums) -> reduce FC + swish ->
-// expand FC + sigmoid -> scale[b][c]; replaces `_se_reduce,_swish,_se_expand,sigmoid`
-// (reference efficientnet/model.py:90-93).  fp32 throughout.  grid = (B, SE_SPLIT): every block
-// rebuilds the mean and the hidden vector (cheap, L2-resident) and produces one slice of the
-// channels, so the launch is SE_SPLIT x B blocks of 16 waves instead of B serial chains.  All
-// loads of a phase are independent and issued before their first use; `we` is stored [sq][C] so
-// the expand FC reads coalesced rows.  The scale is applied by the project GEMM while it loads
-// its A fragments.
-// ------------------------------------------------------------------------------------------------
-#define SE_THREADS 1024
-#define SE_SPLIT 4
-__global__ __launch_bounds__(SE_THREADS) void se_kernel(SeArgs a) {
-  extern __shared__ float sm[];          // mean[C] | hidden[sq] | slice sums [S][C]
-  float* mean = sm;
-  float* hid = sm + a.C;
-  const int b = blockIdx.x;
-  // mean: thread -> (slice, channel), t = sl * C + c; slice sl adds partial rows sl, sl + S, .. (fixed order),
-  // then the S slices of a channel are added up - all 1024 lanes load instead of C of them
-  {
-    const int C = a.C;
-    int S = SE_THREADS / C; if (S < 1) S = 1; if (S > a.nblk) S = a.nblk;
-    float* psum = hid + ((a.sq + 3) & ~3);
-    for (int t = threadIdx.x; t < S * C; t += SE_THREADS) {
-      const int sl = t / C, c = t - sl * C;
-      const float* p = a.partial + (int64_t)b * a.nblk * C + c;
-      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-      int i = sl;
-      for (; i + 3 * S < a.nblk; i += 4 * S) {
-        s0 += p[(int64_t)i * C]; s1 += p[(int64_t)(i + S) * C]; s2 += p[(int64_t)(i + 2 * S) * C]; s3 += p[(int64_t)(i + 3 * S) * C];
-      }
-      for (; i < a.nblk; i += S) s0 += p[(int64_t)i * C];
-      psum[t] = (s0 + s1) + (s2 + s3);
-    }
-    __syncthreads();
-    for (int c = threadIdx.x; c < C; c += SE_THREADS) {
-      float m = 0.f;
-      for (int sl = 0; sl < S; sl++) m += psum[sl * C + c];
-      mean[c] = m * a.inv_hw;
-    }
-  }
-  __syncthreads();
-  // reduce FC: wave w owns rows w, w+16, w+32 (sq <= 48 on every EfficientNet up to B7: rows beyond
-  // that loop again).  ALL weight loads of a wave (3 rows x up to 5 steps of 256 channels) are issued
-  // before the first is consumed: one memory round trip instead of one per step.
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  constexpr int NW = SE_THREADS / 64;
-  constexpr int CIT = 5;                       // 256-channel steps held in registers (C <= 1280)
-  for (int j0 = wave; j0 < a.sq; j0 += 3 * NW) {
-    float s[3] = {0.f, 0.f, 0.f};
-    for (int cb = 0; cb < a.C; cb += 256 * CIT) {
-      f32x4 w[3][CIT];
-#pragma unroll
-      for (int it = 0; it < CIT; it++)
-#pragma unroll
-        for (int q = 0; q < 3; q++) {
-          const int j = j0 + q * NW, c = cb + it * 256 + lane * 4;
-          w[q][it] = (f32x4){0.f, 0.f, 0.f, 0.f};
-          if (j < a.sq && c < a.C) w[q][it] = *reinterpret_cast<const f32x4*>(a.wr + (int64_t)j * a.C + c);
-        }
-#pragma unroll
-      for (int it = 0; it < CIT; it++) {
-        const int c = cb + it * 256 + lane * 4;
-        if (c < a.C) {
-          const f32x4 m = *reinterpret_cast<const f32x4*>(mean + c);
-#pragma unroll
-          for (int q = 0; q < 3; q++) s[q] += w[q][it][0] * m[0] + w[q][it][1] * m[1] + w[q][it][2] * m[2] + w[q][it][3] * m[3];
-        }
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < 3; q++) {
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) s[q] += __shfl_xor(s[q], o);
-      const int j = j0 + q * NW;
-      if (lane == 0 && j < a.sq) hid[j] = swishf(s[q] + a.br[j]);
-    }
-  }
-  // expand FC: a lane's weights we[0..sq)[c] (up to SQR of them: one round trip) are in flight across the
-  // barrier that publishes the hidden vector
-  const int per = (a.C + SE_SPLIT - 1) / SE_SPLIT;
-  const int c0 = blockIdx.y * per, c1 = min(a.C, c0 + per);
-  constexpr int SQR = 48;
-  const int cme = c0 + threadIdx.x;
-  float wv[SQR];
-  if (cme < c1) {
-#pragma unroll
-    for (int j = 0; j < SQR; j++) wv[j] = j < a.sq ? a.we[(int64_t)j * a.C + cme] : 0.f;
-  }
-  __syncthreads();
-  if (cme < c1) {
-    float acc[4] = {a.be[cme], 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int j = 0; j < SQR; j++) if (j < a.sq) acc[j & 3] = fmaf(wv[j], hid[j], acc[j & 3]);
-    for (int j = SQR; j < a.sq; j++) acc[j & 3] = fmaf(a.we[(int64_t)j * a.C + cme], hid[j], acc[j & 3]);
-    a.scale[(int64_t)b * a.C + cme] = sigmoidf((acc[0] + acc[1]) + (acc[2] + acc[3]));
-  }
-  for (int c = cme + SE_THREADS; c < c1; c += SE_THREADS) {        // slices wider than the workgroup (C > 4096)
-    float acc[4] = {a.be[c], 0.f, 0.f, 0.f};
-    for (int j = 0; j < a.sq; j++) acc[j & 3] = fmaf(a.we[(int64_t)j * a.C + c], hid[j], acc[j & 3]);
-    a.scale[(int64_t)b * a.C + c] = sigmoidf((acc[0] + acc[1]) + (acc[2] + acc[3]));
-  }
-}
-void launch_se(const SeArgs& a, hipStream_t s) {
-  int S = SE_THREADS / a.C; if (S < 1) S = 1; if (S > a.nblk) S = a.nblk;
-  const size_t lds = ((size_t)a.C + ((a.sq + 3) & ~3) + (size_t)S * a.C) * sizeof(float);      // mean | hidden | slice sums
-  hipLaunchKernelGGL(se_kernel, dim3(a.B, SE_SPLIT), dim3(SE_THREADS), lds, s, a);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -16,7 +16,8 @@
 //            depthwise conv's padding of the *activated* map (reference utils_extra.py:33-44): zeros
 //   phase C  depthwise taps from LDS (weights in LDS) -> +bias, swish -> global, 16 bytes per lane;
 //            per-lane channel sums for squeeze-excite
-//   phase D  per-wave channel sums (wave butterfly, fixed order) -> partial[b][tile*4 + wave][c]   (no atomics)
+//   phase D  channel sums of the tile (fixed order) -> their partial products with the squeeze-excite
+//            reduce weights -> hpart[b][workgroup][j]   (no atomics; the project GEMM finishes the SE)
 // Blocks without an expand conv (first block of the net) skip phase B: the input tile IS the
 // depthwise input.
 #include <stdlib.h>
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(MBF_THREADS) void mbf_kernel(MbfArgs a) {
       const int nv = PIN * EP * (int)sizeof(T) / 16;               // the whole [PIN][EP] tile in 16-byte vectors
       for (int i = threadIdx.x; i < nv; i += MBF_THREADS) reinterpret_cast<u32x4*>(e_s)[i] = (u32x4){0, 0, 0, 0};
     }
-    for (int base = 0; base < ((a.dbg_skip & 1) ? 0 : n_rows); base += rstride * NB) {
+    for (int base = 0; base < n_rows; base += rstride * NB) {
       raw_t x0[NB], x1[NB];
 #pragma unroll
       for (int j = 0; j < NB; j++) {
@@ -164,7 +165,6 @@ __global__ __launch_bounds__(MBF_THREADS) void mbf_kernel(MbfArgs a) {
       }
     }
   }
-  if (a.dbg_skip & 1) park_weights();
   MSTAMP(1);
   __syncthreads();
   MSTAMP(2);
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(MBF_THREADS) void mbf_kernel(MbfArgs a) {
     // three k-steps of fragments in flight
     const int mpairs = (n_in + 31) >> 5;                           // pairs of 16-pixel m-tiles over the inside pixels
     int ntsh = 0; while ((1 << ntsh) < ntiles) ntsh++;             // pp -> (mp, nt): a shift and a mask
-    for (int pp = wave; pp < ((a.dbg_skip & 2) ? 0 : mpairs << ntsh); pp += MBF_WAVES) {
+    for (int pp = wave; pp < (mpairs << ntsh); pp += MBF_WAVES) {
       const int nt = pp & ((1 << ntsh) - 1), mp = pp >> ntsh;
       if (nt >= ntiles) continue;
       const int m0 = mp * 32 + r, m1 = m0 + 16;
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(MBF_THREADS) void mbf_kernel(MbfArgs a) {
   const int cg = tl & (cgp - 1), pp = tl >> cgsh;                          // pixel pair 0 .. TS*TS/2 - 1
   f32x4* xch = reinterpret_cast<f32x4*>(smem);                             // [4][256] float4: partial sums of waves 4-7
   float sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  const bool item = cg < cgs && pp < TS * TS / 2 && !(a.dbg_skip & 4);
+  const bool item = cg < cgs && pp < TS * TS / 2;
   constexpr int KH = (KS + 1) / 2;
   float acc0[8], acc1[8];
   constexpr int NX = S + KS;
@@ -289,19 +289,47 @@ __global__ __launch_bounds__(MBF_THREADS) void mbf_kernel(MbfArgs a) {
   }
   MSTAMP(5);
 
-  // ---- phase D: channel sums for the squeeze-excite mean, fixed order, no barrier: butterfly over the
-  //      lanes of a wave that share a channel group (lane = cg mod cgp), then lane cg of each of the
-  //      MBF_SUM_ROWS waves that ran phase C writes its row partial[b][tile * MBF_SUM_ROWS + wave][c]
-  //      (se_kernel adds the rows up) ----
-  if (a.partial && !(a.dbg_skip & 8) && wave < MBF_SUM_ROWS) {
-    for (int off = cgp; off < 64; off <<= 1) {
+  // ---- phase D: squeeze-excite.  The mean over the image and the reduce FC are linear in the channel
+  //      sums, so every workgroup contributes the partial products of ITS channels and pixels:
+  //        hpart[b][workgroup][j] = sum_{c in chunk} wr[j][c0 + c] * (sum of this tile's outputs of channel c)
+  //      and the project GEMM (k_pw.hip) adds the rows up, applies 1/HW, bias and swish and runs the
+  //      expand FC in its prologue - no squeeze-excite launch.  Fixed order everywhere (wave butterfly,
+  //      the four depthwise waves added 0..3, lane butterfly): bit-reproducible, no atomics. ----
+  if (a.hpart) {
+    float* ssum = reinterpret_cast<float*>(smem + a.off_e);               // [4][CC]: the expanded tile is dead
+    if (wave < 4) {
+      for (int off = cgp; off < 64; off <<= 1) {
 #pragma unroll
-      for (int c = 0; c < 8; c++) sum[c] += __shfl_xor(sum[c], off, 64);
+        for (int c = 0; c < 8; c++) sum[c] += __shfl_xor(sum[c], off, 64);
+      }
+      if (lane < cgs) {
+        f32x4* d = reinterpret_cast<f32x4*>(ssum + wave * a.CC + lane * 8);
+        d[0] = (f32x4){sum[0], sum[1], sum[2], sum[3]}; d[1] = (f32x4){sum[4], sum[5], sum[6], sum[7]};
+      }
     }
-    if (lane < cgs) {
-      const int tiles = tiles_x * ((a.Ho + TS - 1) / TS);
-      f32x4* d = reinterpret_cast<f32x4*>(a.partial + (((int64_t)b * tiles + tile) * MBF_SUM_ROWS + wave) * a.Cexp + c0 + lane * 8);
-      d[0] = (f32x4){sum[0], sum[1], sum[2], sum[3]}; d[1] = (f32x4){sum[4], sum[5], sum[6], sum[7]};
+    __syncthreads();
+    const int part = threadIdx.x & 7, ch = part * 8;                      // 8 lanes share one hidden unit j
+    float cs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (ch < cc) {
+#pragma unroll
+      for (int w4 = 0; w4 < 4; w4++) {
+        const f32x4* sp = reinterpret_cast<const f32x4*>(ssum + w4 * a.CC + ch);
+        const f32x4 s0 = sp[0], s1 = sp[1];
+#pragma unroll
+        for (int c = 0; c < 4; c++) { cs[c] += s0[c]; cs[4 + c] += s1[c]; }
+      }
+    }
+    const int tiles = tiles_x * ((a.Ho + TS - 1) / TS);
+    float* hrow = a.hpart + ((int64_t)b * tiles * chunks + blockIdx.x) * a.sqp;
+    for (int j = threadIdx.x >> 3; j < ((a.sq + 63) & ~63); j += MBF_THREADS / 8) {
+      float dot = 0.f;
+      if (j < a.sq && ch < cc) {
+        const f32x4* wp = reinterpret_cast<const f32x4*>(a.se_wr + (int64_t)j * a.Cexp + c0 + ch);
+        const f32x4 w0 = wp[0], w1 = wp[1];
+        dot = ((w0[0] * cs[0] + w0[1] * cs[1]) + (w0[2] * cs[2] + w0[3] * cs[3])) + ((w1[0] * cs[4] + w1[1] * cs[5]) + (w1[2] * cs[6] + w1[3] * cs[7]));
+      }
+      dot += __shfl_xor(dot, 1, 64); dot += __shfl_xor(dot, 2, 64); dot += __shfl_xor(dot, 4, 64);
+      if (part == 0 && j < a.sq) hrow[j] = dot;
     }
   }
 #ifdef HEP_MBF_TRACE
@@ -372,9 +400,7 @@ static void launch_mbf_t(const MbfArgs& a, dim3 grid, hipStream_t s) {
   else hipLaunchKernelGGL((mbf_kernel<BF16, 5, 2>), grid, dim3(MBF_THREADS), a.lds_bytes, s, a);
 }
 void launch_mbf(const MbfArgs& a_, hipStream_t s) {
-  MbfArgs a = a_;
-  static const int skip = getenv("HEP_MBF_SKIP") ? atoi(getenv("HEP_MBF_SKIP")) : 0;   // timing experiments only (results are wrong)
-  a.dbg_skip = skip;
+  const MbfArgs& a = a_;
   const int tiles = ((a.Wo + 7) / 8) * ((a.Ho + 7) / 8), chunks = (a.Cexp + a.CC - 1) / a.CC;
   dim3 grid(tiles * chunks, a.B);
   if (a.bf16) launch_mbf_t<true>(a, grid, s); else launch_mbf_t<false>(a, grid, s);

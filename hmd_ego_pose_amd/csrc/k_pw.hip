@@ -2,6 +2,13 @@
 //
 //   out[m, n] = act( sum_k (A[m,k] * se[b(m),k]) * W[n,k] + bias[n] ) (+ res[m,n])
 //
+// se[b,:] is the squeeze-excite scale of the project convs.  It is finished HERE, in the prologue of
+// the GEMM that consumes it (reference efficientnet/model.py:86-93: `_se_reduce,_swish,_se_expand,
+// sigmoid`): the depthwise kernels leave hpart[b][row][j], the partial products of the reduce FC with
+// their channel sums (mean and FC are linear), and every workgroup adds the rows of its image, applies
+// 1/HW, bias and swish, runs the expand FC for all K input channels into LDS and multiplies its A
+// fragments by it.  No squeeze-excite launch, no scale tensor in HBM.
+//
 // A is the NHWC activation viewed as [M = B*H*W, K] row-major, W the folded conv weight
 // [N, K] (K contiguous, exactly PyTorch's [Cout, Cin]).  Replaces the library calls behind
 // `_expand_conv/_bn0/_swish`, `_project_conv/_bn2/+inputs` (reference efficientnet/model.py:78-81,
@@ -32,7 +39,6 @@ template <> struct Frag<false> { typedef f32x4 raw; static constexpr int KSTEP =
 template <bool BF16, int MT, int NT>
 struct Step {
   typename Frag<BF16>::raw a[MT];   // activation fragments
-  f32x4 s0[MT], s1[MT];             // squeeze-excite scales for them
   typename Frag<BF16>::raw w[NT];   // weight fragments
 };
 
@@ -64,11 +70,63 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
     kbeg = min(K, wave * per * F::KSTEP); kend = min(K, (wave + 1) * per * F::KSTEP);
   }
 
+  // ---- squeeze-excite prologue: scale_s[image - img0][k] for the images this workgroup's rows belong to ----
+  extern __shared__ __attribute__((aligned(16))) float se_s[];
+  const bool SE = a.hpart != nullptr;
+  int img0 = 0;
+  if (SE) {
+    constexpr int ROWS = MODE == 0 ? 64 * MT : 16 * MT;
+    const int mfirst = mblk * ROWS, mlast = min(M, mfirst + ROWS) - 1;
+    img0 = mfirst / a.HW;
+    const int img1 = mlast / a.HW, sqp = a.sqp, sq = a.sq;
+    float* hid_s = se_s + a.se_nimg * K;          // [sqp]
+    float* red_s = hid_s + sqp;                   // [G][sqp] row sums of the G helper groups
+    const int G = max(1, 256 / sqp);
+    const int grp = threadIdx.x / sqp, j = threadIdx.x - grp * sqp;
+    for (int img = img0; img <= img1; img++) {
+      // hidden[j] = swish(inv_hw * sum_rows hpart[img][row][j] + br[j]): G groups each add every G-th row,
+      // then the groups are added up - fixed order
+      if (grp < G && j < sq) {
+        const float* hp = a.hpart + (int64_t)img * a.se_rows * sqp + j;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int row = grp;
+        for (; row + 3 * G < a.se_rows; row += 4 * G) {
+          s0 += hp[(int64_t)row * sqp]; s1 += hp[(int64_t)(row + G) * sqp]; s2 += hp[(int64_t)(row + 2 * G) * sqp]; s3 += hp[(int64_t)(row + 3 * G) * sqp];
+        }
+        for (; row < a.se_rows; row += G) s0 += hp[(int64_t)row * sqp];
+        red_s[grp * sqp + j] = (s0 + s1) + (s2 + s3);
+      }
+      __syncthreads();
+      if (threadIdx.x < sqp) {
+        float h = 0.f;
+        if (threadIdx.x < sq) {
+          float sacc = 0.f;
+          for (int q = 0; q < G; q++) sacc += red_s[q * sqp + threadIdx.x];
+          h = swishf(fmaf(sacc, a.inv_hw, a.se_br[threadIdx.x]));
+        }
+        hid_s[threadIdx.x] = h;                  // padding entries are exact zeros
+      }
+      __syncthreads();
+      // expand FC + sigmoid: one weight row we[k][0..sqp) per thread and k
+      float* sc = se_s + (img - img0) * K;
+      for (int k = threadIdx.x; k < K; k += 256) {
+        const f32x4* wp = reinterpret_cast<const f32x4*>(a.se_we + (int64_t)k * sqp);
+        float e0 = a.se_be[k], e1 = 0.f, e2 = 0.f, e3 = 0.f;
+        for (int j4 = 0; j4 < sqp; j4 += 4) {
+          const f32x4 w = wp[j4 >> 2], h = *reinterpret_cast<const f32x4*>(hid_s + j4);
+          e0 = fmaf(w[0], h[0], e0); e1 = fmaf(w[1], h[1], e1); e2 = fmaf(w[2], h[2], e2); e3 = fmaf(w[3], h[3], e3);
+        }
+        sc[k] = sigmoidf((e0 + e1) + (e2 + e3));
+      }
+      __syncthreads();
+    }
+  }
+
   int mrow[MT]; bool mok[MT]; int mimg[MT];
 #pragma unroll
   for (int i = 0; i < MT; i++) {
     mrow[i] = m0 + i * 16 + r; mok[i] = mrow[i] < M;
-    mimg[i] = (a.se && mok[i]) ? mrow[i] / a.HW : 0;
+    mimg[i] = (SE && mok[i]) ? mrow[i] / a.HW - img0 : 0;
   }
   f32x4 acc[MT][NT];
 #pragma unroll
@@ -84,15 +142,6 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
       raw_t v = {};
       if (kok && mok[i]) v = *reinterpret_cast<const raw_t*>(A + (int64_t)mrow[i] * K + k);
       st.a[i] = v;
-      if (a.se) {
-        f32x4 s0 = (f32x4){0.f, 0.f, 0.f, 0.f}, s1 = s0;
-        if (kok && mok[i]) {
-          const f32x4* sp = reinterpret_cast<const f32x4*>(a.se + (int64_t)mimg[i] * K + k);
-          s0 = sp[0];
-          if (BF16) s1 = sp[1];
-        }
-        st.s0[i] = s0; st.s1[i] = s1;
-      }
     }
 #pragma unroll
     for (int j = 0; j < NT; j++) {
@@ -101,14 +150,18 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
       st.w[j] = v;
     }
   };
-  auto compute = [&](Step<BF16, MT, NT>& st) {
+  auto compute = [&](Step<BF16, MT, NT>& st, int kk) {
+    // squeeze-excite scales of this lane's k run (LDS; rows outside M or k >= kend hold zeros in A anyway)
+    const int ks = min(kk + F::KLANE * g, K - F::KLANE);
     if constexpr (BF16) {
       bf16x8 bfrag[MT];
 #pragma unroll
       for (int i = 0; i < MT; i++) {
         u32x4 raw = st.a[i];
-        if (a.se) {
-          const float s[8] = {st.s0[i][0], st.s0[i][1], st.s0[i][2], st.s0[i][3], st.s1[i][0], st.s1[i][1], st.s1[i][2], st.s1[i][3]};
+        if (SE) {
+          const f32x4* sp = reinterpret_cast<const f32x4*>(se_s + mimg[i] * K + ks);
+          const f32x4 s0 = sp[0], s1 = sp[1];
+          const float s[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
 #pragma unroll
           for (int q = 0; q < 4; q++)
             raw[q] = pack_bf16x2(__uint_as_float(raw[q] << 16) * s[2 * q], __uint_as_float(raw[q] & 0xffff0000u) * s[2 * q + 1]);
@@ -125,7 +178,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
 #pragma unroll
       for (int i = 0; i < MT; i++) {
         f32x4 x = st.a[i];
-        if (a.se) x *= st.s0[i];
+        if (SE) x *= *reinterpret_cast<const f32x4*>(se_s + mimg[i] * K + ks);
 #pragma unroll
         for (int j = 0; j < NT; j++)
 #pragma unroll
@@ -141,10 +194,10 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
     int kk = kbeg;
     for (; kk + F::KSTEP < kend; kk += F::KSTEP) {
       load(nxt, kk + F::KSTEP);
-      compute(cur);
+      compute(cur, kk);
       cur = nxt;
     }
-    compute(cur);
+    compute(cur, kk);
   }
 
   if (MODE == 2) {   // meet the four K-slices in LDS; wave w finishes n-tiles j = w, w+4, ...
@@ -188,9 +241,11 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
 
 template <bool BF16, int MT, int MODE>
 static void launch_nt(const PwArgs& a, dim3 grid, hipStream_t s) {
+  // dynamic LDS of the squeeze-excite prologue: scale [se_nimg][K] | hidden [sqp] | helper-group row sums [<= 256]
+  const size_t lds = a.hpart ? ((size_t)a.se_nimg * a.K + a.sqp + 256 + a.sqp) * sizeof(float) : 0;
   switch (a.NT) {
-#define CASE(n) case n: if (a.act == ACT_SWISH) hipLaunchKernelGGL((pw_gemm_kernel<BF16, MT, n, MODE, ACT_SWISH>), grid, dim3(256), 0, s, a); \
-                else hipLaunchKernelGGL((pw_gemm_kernel<BF16, MT, n, MODE, ACT_NONE>), grid, dim3(256), 0, s, a); break;
+#define CASE(n) case n: if (a.act == ACT_SWISH) hipLaunchKernelGGL((pw_gemm_kernel<BF16, MT, n, MODE, ACT_SWISH>), grid, dim3(256), lds, s, a); \
+                else hipLaunchKernelGGL((pw_gemm_kernel<BF16, MT, n, MODE, ACT_NONE>), grid, dim3(256), lds, s, a); break;
     CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
 #undef CASE
   }

@@ -165,7 +165,7 @@ __global__ __launch_bounds__(SEP_THREADS_OF(MODE), MODE == 1 ? SEP_M1_WAVES : 4)
   {
     const int cg = threadIdx.x & ((1 << cgsh) - 1);
     if (cg < CG)
-      for (int pos = threadIdx.x >> cgsh; pos < ((a.dbg_skip & 1) ? 0 : HS * HS); pos += SEP_THREADS >> cgsh) {
+      for (int pos = threadIdx.x >> cgsh; pos < HS * HS; pos += SEP_THREADS >> cgsh) {
         const int hy = TS == 16 ? pos / 18 : (TS == 8 ? pos / 10 : pos / 6), hx = pos - hy * HS;
         const int y = y0 + hy - 1, x = x0 + hx - 1;
         float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(SEP_THREADS_OF(MODE), MODE == 1 ? SEP_M1_WAVES : 4)
   {
     const int cg = threadIdx.x & ((1 << cgsh) - 1);
     if (cg < CG)
-      for (int p = threadIdx.x >> cgsh; p < ((a.dbg_skip & 2) ? 0 : TS * TS); p += SEP_THREADS >> cgsh) {
+      for (int p = threadIdx.x >> cgsh; p < TS * TS; p += SEP_THREADS >> cgsh) {
         const int py = p >> tssh, px = p & (TS - 1);
         float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(SEP_THREADS_OF(MODE), MODE == 1 ? SEP_M1_WAVES : 4)
   T* otile_t = reinterpret_cast<T*>(smem);                // [TS*TS][Nc] dtype (maps)
   // (m-tile, n-tile) pairs are dealt round-robin to the waves; pair -> (nt, mt) is a shift and a mask
   int mtsh = 0; while ((1 << mtsh) < mtv) mtsh++;
-  for (int pair = wave; pair < ((a.dbg_skip & 4) ? 0 : sg.tilesN << mtsh); pair += SEP_WAVES) {
+  for (int pair = wave; pair < (sg.tilesN << mtsh); pair += SEP_WAVES) {
     const int nt = pair >> mtsh, mt = pair & ((1 << mtsh) - 1);
     if (mt >= mtv) continue;
     const int m = mt * 16 + r;
@@ -239,8 +239,7 @@ __global__ __launch_bounds__(SEP_THREADS_OF(MODE), MODE == 1 ? SEP_M1_WAVES : 4)
   __syncthreads();
 
   // ---- phase 4: coalesced copy-out ----
-  if (a.dbg_skip & 8) {
-  } else if (sg.out_f32) {
+  if (sg.out_f32) {
     // head result [B, N_anchors, K]: pixel p owns 9*K consecutive floats; this segment's Nc columns
     float* o = reinterpret_cast<float*>(sg.out) + (int64_t)b * sg.out_bstride + sg.out_off;
     const int npx = rows_valid * cols_valid;
@@ -299,9 +298,7 @@ int sep_prepare(void) {
 }
 
 void launch_sep(const SepArgs& a_, hipStream_t s) {
-  SepArgs a = a_;
-  static const int skip = getenv("HEP_SEP_SKIP") ? atoi(getenv("HEP_SEP_SKIP")) : 0;   // timing experiments only (results are wrong)
-  a.dbg_skip = skip;
+  const SepArgs& a = a_;
   const int mode = a.chain ? 2 : (a.nseg == 1 ? 0 : 1);
   dim3 grid(mode == 2 ? 1 : a.total_tiles, a.B);
   const dim3 block(SEP_THREADS_OF(mode));

@@ -111,7 +111,7 @@ template <bool BF16, int CW, bool HDR> struct TowerCfg {
 };
 
 template <bool BF16, int CW, bool HDR>
-__global__ __launch_bounds__(256, BF16 ? 4 : 2) void tower_kernel(const SepSeg* __restrict__ segs, const int* __restrict__ tile_seg, int B, int ipb, int dbg) {
+__global__ __launch_bounds__(256, BF16 ? 4 : 2) void tower_kernel(const SepSeg* __restrict__ segs, const int* __restrict__ tile_seg, int B, int ipb) {
   typedef Frag<BF16> F;
   typedef typename F::raw raw_t;
   typedef typename Vec8<BF16>::elem T;
@@ -233,11 +233,11 @@ __global__ __launch_bounds__(256, BF16 ? 4 : 2) void tower_kernel(const SepSeg* 
     }
   };
   raw_t* xa_s = reinterpret_cast<raw_t*>(smem + Cfg::OFF_XA) + wave * KS * 64 + lane;
-  if (!(dbg & 2)) load_group(0, 0);
+  load_group(0, 0);
   TSTAMP_NOWAIT(2);                    // staging + first taps issued
   __syncthreads();                     // weights are in LDS; the first taps are in flight
   TSTAMP_NOWAIT(3);                    // barrier passed
-  if (y0 >= h || x0 >= w || (dbg & 1)) return;      // patch entirely outside the map
+  if (y0 >= h || x0 >= w) return;      // patch entirely outside the map
 
   // pointwise weight fragment of MFMA row `row`, k-step ks (zero where k >= CW)
   auto wfrag = [&](int row, int ks) -> raw_t {
@@ -258,14 +258,14 @@ __global__ __launch_bounds__(256, BF16 ? 4 : 2) void tower_kernel(const SepSeg* 
   if constexpr (HALO) {
     // park this image's halo (the previous image's tap reads are done: LDS executes a wave in order),
     // then put the next image's halo in flight
-    if (!(dbg & 2)) {
+    {
 #pragma unroll
       for (int j = 0; j < NV; j++) if (hdst[j] >= 0) *reinterpret_cast<raw_t*>(halo + hdst[j]) = hv[j];
       if (bi + 1 < nimg) load_group(bi + 1, 0);
     }
   }
 #pragma unroll 1
-  for (int gi = 0; gi < ((dbg & 2) ? 0 : NG); gi++) {
+  for (int gi = 0; gi < NG; gi++) {
 #pragma unroll
     for (int j = 0; j < G; j++) {
       const int ks = gi * G + j;
@@ -287,9 +287,8 @@ __global__ __launch_bounds__(256, BF16 ? 4 : 2) void tower_kernel(const SepSeg* 
     }
     if (!HALO && gi + 1 < NG) load_group(bi, gi + 1);
   }
-  if (!HALO && bi + 1 < nimg && !(dbg & 2)) load_group(bi + 1, 0);     // next image's taps fly during the MFMA phase
+  if (!HALO && bi + 1 < nimg) load_group(bi + 1, 0);     // next image's taps fly during the MFMA phase
   TSTAMP_NOWAIT(4);                    // depthwise done (fragments in LDS)
-  if (dbg & 4) continue;
   if constexpr (!HDR) {
     // ---- maps: lane (r, g) owns channels g*RUN + 4*nt .. +3 of pixel r for every n-tile nt ----
     constexpr int NT = Cfg::NTMAP, RUN = 4 * NT;
@@ -383,17 +382,16 @@ int tower_supports(int C) {
 int tower_map_tiles(int C) { return (((C + 15) / 16) + 1) & ~1; }      // n-tiles of a map layer (even)
 
 template <bool BF16, int CW, bool HDR>
-static void launch_one(const SepArgs& a, dim3 grid, hipStream_t s, int ipb, int dbg) {
+static void launch_one(const SepArgs& a, dim3 grid, hipStream_t s, int ipb) {
   typedef TowerCfg<BF16, CW, HDR> Cfg;
-  hipLaunchKernelGGL((tower_kernel<BF16, CW, HDR>), grid, dim3(256), Cfg::LDS, s, a.segs, a.tile_seg, a.B, ipb, dbg);
+  hipLaunchKernelGGL((tower_kernel<BF16, CW, HDR>), grid, dim3(256), Cfg::LDS, s, a.segs, a.tile_seg, a.B, ipb);
 }
 
 template <int CW>
 static void launch_w(const SepArgs& a, dim3 grid, hipStream_t s, int ipb) {
   const bool hdr = a.direct == 2;
-  static const int dbg = getenv("HEP_TOWER_SKIP") ? atoi(getenv("HEP_TOWER_SKIP")) : 0;   // timing experiments only (results are wrong)
-  if (a.bf16) { if (hdr) launch_one<true, CW, true>(a, grid, s, ipb, dbg); else launch_one<true, CW, false>(a, grid, s, ipb, dbg); }
-  else { if (hdr) launch_one<false, CW, true>(a, grid, s, ipb, dbg); else launch_one<false, CW, false>(a, grid, s, ipb, dbg); }
+  if (a.bf16) { if (hdr) launch_one<true, CW, true>(a, grid, s, ipb); else launch_one<true, CW, false>(a, grid, s, ipb); }
+  else { if (hdr) launch_one<false, CW, true>(a, grid, s, ipb); else launch_one<false, CW, false>(a, grid, s, ipb); }
 }
 
 template <int CW>

@@ -63,51 +63,77 @@ def broadcast_state_dict(state: Dict[str, torch.Tensor], device: torch.device, s
     return out
 
 
+def _wire(t: torch.Tensor) -> torch.Tensor:
+    """What actually goes into send/recv: device memory over RCCL; gloo (CPU wiring tests, or the one-GPU
+    wiring run of bench.py) has no point-to-point ops for device tensors, so those are staged on the host."""
+    return t.cpu() if (t.is_cuda and dist.get_backend() == "gloo") else t
+
+
 def scatter_frames(global_frames: Optional[torch.Tensor], global_batch: int, shape: Tuple[int, ...], device: torch.device,
-                   src: int = 0) -> torch.Tensor:
-    """Rank ``src`` holds [global_batch, *shape]; every rank returns its slice."""
+                   src: int = 0, dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    """Rank ``src`` holds [global_batch, *shape] (uint8 frames before preprocessing: 4x fewer bytes than fp32);
+    every rank returns its contiguous slice.  Point to point: every peer has its own xGMI link to the root, and
+    the slices of a contiguous tensor on the root are sent in place (no staging copy); the sends are posted as
+    one group."""
     rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
     lo, hi = shard_range(global_batch, rank, world)
     if world == 1:
         return global_frames[lo:hi].to(device)
-    mine = torch.empty((hi - lo, *shape), dtype=torch.float32, device=device)
     if rank == src:
-        reqs = []
+        g = global_frames if global_frames.is_contiguous() else global_frames.contiguous()
+        if g.device != device and dist.get_backend() != "gloo":
+            g = g.to(device)
+        ops = []
         for r in range(world):
             l, h = shard_range(global_batch, r, world)
-            if r == src:
-                mine.copy_(global_frames[l:h])
-            elif h > l:
-                reqs.append(dist.isend(global_frames[l:h].contiguous().to(device), r))
+            if r != src and h > l:
+                ops.append(dist.P2POp(dist.isend, _wire(g[l:h]), r))
+        reqs = dist.batch_isend_irecv(ops) if ops else []
+        mine = g[lo:hi].to(device)
         for q in reqs:
             q.wait()
-    elif hi > lo:
-        dist.recv(mine, src)
+        return mine
+    mine = torch.empty((hi - lo, *shape), dtype=dtype, device=device)
+    if hi > lo:
+        buf = _wire(mine)
+        dist.recv(buf, src)
+        if buf is not mine:
+            mine.copy_(buf)
     return mine
 
 
 def gather_detections(det: Dict[str, torch.Tensor], global_batch: int, dst: int = 0) -> Optional[Dict[str, torch.Tensor]]:
-    """Gather the per-frame detection rows of every rank on ``dst`` in global frame order."""
+    """Gather the per-frame detection rows of every rank on ``dst`` in global frame order (post-filter rows only:
+    <= 30 KB per frame, never the 3.6 MB of raw heads).  All receives of the root are posted as one group."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return det
     rank, world = dist.get_rank(), dist.get_world_size()
-    out: Dict[str, torch.Tensor] = {}
-    for k in sorted(det):
+    keys = sorted(det)
+    if rank != dst:
+        ops = [dist.P2POp(dist.isend, _wire(det[k].contiguous()), dst) for k in keys if det[k].shape[0] > 0]
+        for q in (dist.batch_isend_irecv(ops) if ops else []):
+            q.wait()
+        return None
+    bufs: Dict[str, List[torch.Tensor]] = {k: [] for k in keys}
+    ops, staged = [], []
+    for k in keys:
         t = det[k].contiguous()
-        if rank == dst:
-            parts: List[torch.Tensor] = []
-            for r in range(world):
-                l, h = shard_range(global_batch, r, world)
-                if r == dst:
-                    parts.append(t)
-                elif h > l:
-                    buf = torch.empty((h - l, *t.shape[1:]), dtype=t.dtype, device=t.device)
-                    dist.recv(buf, r)
-                    parts.append(buf)
-            out[k] = torch.cat(parts, 0)
-        elif t.shape[0] > 0:
-            dist.send(t, dst)
-    return out if rank == dst else None
+        for r in range(world):
+            l, h = shard_range(global_batch, r, world)
+            if r == dst:
+                bufs[k].append(t)
+            elif h > l:
+                buf = torch.empty((h - l, *t.shape[1:]), dtype=t.dtype, device=t.device)
+                w = _wire(buf)
+                ops.append(dist.P2POp(dist.irecv, w, r))
+                staged.append((buf, w))
+                bufs[k].append(buf)
+    for q in (dist.batch_isend_irecv(ops) if ops else []):
+        q.wait()
+    for buf, w in staged:
+        if w is not buf:
+            buf.copy_(w)
+    return {k: torch.cat(v, 0) for k, v in bufs.items()}
 
 
 def max_over_ranks(seconds: float, device: torch.device) -> float:

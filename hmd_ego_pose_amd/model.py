@@ -276,7 +276,7 @@ class HMDEgoPose(nn.Module):
         """BatchNorm is folded into the convolutions at pack time; nothing to freeze."""
 
     def init_backbone(self, path):
-        state = torch.load(path, map_location="cpu")
+        state = torch.load(path, map_location="cpu", weights_only=True)
         try:
             print(self.load_state_dict(state, strict=True))
         except RuntimeError as e:

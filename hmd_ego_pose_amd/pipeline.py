@@ -7,14 +7,17 @@ same weights) take the submitted batches round-robin on ``depth`` HIP streams.  
 batch 16, phi 0, bf16: 18.7k frames/s with one batch in flight, 39.4k with four (the chip has
 four hardware queues per process; more streams time-slice and lose).
 
-    pool = InflightPool(state_dict, phi=0, size=256, max_batch=16, precision="bf16", depth=4)
+    pool = InflightPool(state_dict, phi=0, size=256, max_batch=16, precision="bf16", depth=5)
     for frames, camera in loader:                 # frames: fp32 [B,3,S,S] on the GPU
         done = pool.submit(frames, camera)        # returns the oldest finished result or None
-        if done is not None: consume(done)
+        if done is not None: consume(done)        # ... before the next submit()
     for done in pool.drain(): consume(done)
 
-Every result is a dict of tensors owned by the pool slot that produced it: they stay valid
-until that slot is submitted to again (``depth`` submits later).
+``submit`` enqueues on a FREE slot and then hands back the oldest batch in flight (synchronised), whose
+slot is the one the next ``submit`` will reuse.  A returned dict of tensors is owned by its slot and
+stays untouched until the NEXT call of ``submit``/``drain``: nothing is enqueued on those buffers while
+the caller reads them (consume or copy them before submitting again).  While the caller consumes,
+``depth - 1`` batches are in flight, so ``depth=5`` keeps the four hardware queues busy.
 """
 from __future__ import annotations
 
@@ -58,17 +61,17 @@ class InflightPool:
         return {k: v[:b] for k, v in self.slots[d].items()}
 
     def submit(self, frames: torch.Tensor, camera: torch.Tensor) -> Optional[Dict[str, torch.Tensor]]:
-        """Enqueue forward + box/translation decode of ``frames`` on the next slot.  Returns the result
-        that slot held before (synchronised), or None while the pool is still filling."""
+        """Enqueue forward + box/translation decode of ``frames`` on a free slot.  Returns the oldest batch
+        in flight (synchronised) once every slot is occupied, else None.  The returned tensors are not
+        written again before the next call of ``submit`` (the slot they live in is the next one to be reused)."""
         d = self._next
-        self._next = (d + 1) % len(self.sessions)
-        done = self._collect(d)
+        assert self._busy[d] is None, "slot was not collected"      # invariant: the slot submitted to is always free
         sess, st, out = self.sessions[d], self.streams[d], self.slots[d]
         b = frames.shape[0]
         if not frames.is_cuda or frames.dtype != torch.float32 or tuple(frames.shape[1:]) != (3, sess.size, sess.size) or b > sess.max_batch:
             raise ValueError(f"expected float32 ROCm frames [<= {sess.max_batch},3,{sess.size},{sess.size}]")
         cam = camera.to(self.device, torch.float32).contiguous()
-        st.wait_stream(torch.cuda.current_stream(self.device))      # the caller produced `frames` on its own stream
+        st.wait_stream(torch.cuda.current_stream(self.device))      # the caller produced `frames` (and read this slot) on its own stream
         lib = _capi.lib()
         strides = (ctypes.c_int64 * 4)(*frames.stride())
         heads = [out[k] for k in ("regression", "classification", "rotation", "translation_raw", "hand")]
@@ -76,7 +79,8 @@ class InflightPool:
         _capi.check(lib.hep_decode_device(sess.handle, out["regression"].data_ptr(), out["translation_raw"].data_ptr(), cam.data_ptr(), b,
                                           out["boxes"].data_ptr(), out["translation"].data_ptr(), st.cuda_stream))
         self._busy[d], self._inputs[d] = b, (frames, cam)
-        return done
+        self._next = (d + 1) % len(self.sessions)
+        return self._collect(self._next)          # frees the slot the next submit uses; None while the pool is filling
 
     def drain(self) -> Iterator[Dict[str, torch.Tensor]]:
         """Results still in flight, oldest first."""

@@ -6,8 +6,13 @@ Tolerances
   fp32 mode  : |hip - oracle| <= 1e-3 absolute on every output (north_star); observed ~1e-4.
                The oracle itself is pinned to the reference at 1e-5 (tests/test_oracle_golden.py);
                the golden slices are compared at 1e-3 + 1e-4 relative as well.
-  bf16 mode  : reported, and bounded loosely (mean |err| / mean |ref| < 6 % after ~100 layers of
-               bf16 storage, fp32 accumulate) - index parity is asserted in fp32 only.
+  bf16 mode  : gated against the bf16-EMULATING oracle (oracle.forward_emulated: BN folded, every stored
+               activation and every pointwise weight rounded to bf16 where the kernels round, fp32
+               accumulate): per head and per stage tensor max |hip - emu| <= BF16_TOL_MAX * max |emu| and
+               mean |hip - emu| <= BF16_TOL_MEAN * mean |emu|.  The remaining difference is fp32 summation
+               order and exp/rcp ulps flipping an occasional bf16 rounding (1 flip = 2^-8 relative on one
+               element).  The drift of bf16 storage itself against the fp32 oracle (2.5-4 % mean relative
+               on the seeded weights) is reported, not gated.  Index parity is asserted in fp32 only.
   indices    : anchor indices out of the filter are bit-exact vs the oracle given the same scores.
 """
 import ctypes
@@ -19,6 +24,8 @@ import torch
 from tests._util import CAMS, CASES, check_digest, golden_case, seeded_input, strides_for
 
 pytestmark = pytest.mark.gpu
+
+BF16_TOL_MAX, BF16_TOL_MEAN = 2e-2, 2e-3     # see the module docstring; measured values are printed by the tests
 
 
 @pytest.fixture(scope="module")
@@ -91,16 +98,11 @@ def test_other_widths_match_oracle(api, phi):
         # north-star configurations (phi 0 @ 256, phi 3 @ 512) sit at ~5e-5 and keep the 1e-3 gate above
         tol = 1e-3 if phi < 4 else 3e-3
         assert err <= tol, f"phi {phi} {k}: max |hip - oracle| / max(1, |oracle|) = {err:.3e}"
+    emu = api["R"].forward_emulated(sd, x, phi)
     s = api["Session"](sd, phi, size, batch, "bf16")
     out = s.forward(x.cuda())
     torch.cuda.synchronize()
-    for name, a, b in zip(("regression", "classification", "rotation", "translation_raw", "hand"), out[1:], ref[1:]):
-        a = a.float().cpu()
-        assert torch.isfinite(a).all(), name
-        rel = (a - b).abs().mean().item() / max(b.abs().mean().item(), 1e-6)
-        print(f"phi {phi} bf16 {name}: mean|err|/mean|ref| = {rel:.4f}")
-        # (phi 4: 23 blocks + 7 BiFPN cells of seeded weights shrink the signal; the fp32 check above is the parity gate)
-        assert rel < (0.06 if phi < 4 else 0.25), (phi, name, rel)
+    _check_bf16(f"phi {phi}", dict(zip(HEADS, [t.float().cpu() for t in out[1:]])), dict(zip(HEADS, emu[1:])))
     s.close()
 
 
@@ -129,20 +131,47 @@ def test_ragged_tiles_match_oracle(api, size, batch):
     s.close()
 
 
-def test_bf16_forward_error_is_bounded(api):
-    phi, size, batch, seed = 0, 256, 4, 0
+HEADS = ("regression", "classification", "rotation", "translation_raw", "hand")
+
+
+def _check_bf16(label, got, want):
+    """max / mean error of the bf16 session against the bf16-emulating oracle, per tensor."""
+    for k, w in want.items():
+        g = got[k]
+        assert g.shape == w.shape and torch.isfinite(g).all(), (label, k)
+        emax = (g - w).abs().max().item() / max(w.abs().max().item(), 1e-6)
+        emean = (g - w).abs().mean().item() / max(w.abs().mean().item(), 1e-6)
+        print(f"{label} bf16 {k}: max|err|/max|emu| = {emax:.2e}, mean|err|/mean|emu| = {emean:.2e}")
+        assert emax <= BF16_TOL_MAX and emean <= BF16_TOL_MEAN, (label, k, emax, emean)
+
+
+@pytest.mark.parametrize("phi,size,batch", [(0, 256, 16), (3, 512, 8)])
+def test_bf16_matches_bf16_emulating_oracle(api, phi, size, batch):
+    """BASELINE configs 1 and 3 (phi 0 @ 256 batch 16, phi 3 @ 512 batch 8) in the benchmarked dtype: every head
+    and every stage tensor (stem, each MBConv block, each BiFPN cell output) against the oracle that rounds where
+    the kernels round."""
+    seed = 0
     sd = api["sd"](phi, seed)
     x = torch.from_numpy(seeded_input((batch, 3, size, size), seed))
+    trace = {}
+    emu = api["R"].forward_emulated(sd, x, phi, trace)
     ref = api["R"].forward(sd, x, phi)
-    s = api["Session"](sd, phi, size, batch, "bf16")
+    s = api["Session"](sd, phi, size, batch, "bf16", flags=api["capi"].FLAG_KEEP_INTERMEDIATES)
     out = s.forward(x.cuda())
     torch.cuda.synchronize()
-    for name, a, b in zip(("regression", "classification", "rotation", "translation_raw", "hand"), out[1:], ref[1:]):
-        a = a.float().cpu()
-        assert not torch.isnan(a).any()
-        rel = (a - b).abs().mean().item() / b.abs().mean().item()
-        print(f"bf16 {name}: mean|err|/mean|ref| = {rel:.4f}, max|err| = {(a - b).abs().max().item():.3f}")
-        assert rel < 0.06, (name, rel)
+    got = dict(zip(HEADS, [t.float().cpu() for t in out[1:]]))
+    for name, r_, e_ in zip(HEADS, ref[1:], emu[1:]):
+        print(f"phi {phi} {name}: bf16 storage drift vs the fp32 oracle: mean|emu - fp32|/mean|fp32| = {(e_ - r_).abs().mean().item() / r_.abs().mean().item():.4f}, "
+              f"hip: {(got[name] - r_).abs().mean().item() / r_.abs().mean().item():.4f}")
+    _check_bf16(f"phi {phi} @ {size} b{batch}", got, dict(zip(HEADS, emu[1:])))
+    stages, wants = {}, {}
+    for k, v in trace.items():
+        name = k if not k.startswith("bifpn") else f"c{k[5:k.index('_')]}.p{k[-1]}_out"
+        stages[name] = s.stage(name, batch)
+        wants[name] = v.permute(0, 2, 3, 1)
+    _check_bf16(f"phi {phi} @ {size} b{batch}", stages, wants)
+    for l, f in enumerate(out[0]):      # exported feature maps = the last BiFPN cell
+        assert torch.equal(f.float().cpu().permute(0, 2, 3, 1), stages[f"c{api['R']._FPN_REPEATS[phi] - 1}.p{l + 3}_out"])
     s.close()
 
 
@@ -198,8 +227,10 @@ def test_decode_and_filter_match_oracle(api):
     boxes, trans = s.decode(reg, trn, cam)
     ob = D.decode_boxes(anchors, reg.cpu().numpy(), size)
     ot = D.decode_translation(t_anchors, trn.cpu().numpy(), cam.cpu().numpy())
-    assert np.allclose(boxes.cpu().numpy(), ob, rtol=1e-5, atol=1e-3)
-    assert np.allclose(trans.cpu().numpy(), ot, rtol=1e-5, atol=1e-2)
+    assert np.allclose(boxes.cpu().numpy(), ob, rtol=1e-5, atol=1e-3)       # expf differs from numpy's exp by ulps, then cx -+ w/2 cancels
+    # translation: + - * / only, same operation order, correctly rounded division on both sides -> within 2 ulp
+    gt = trans.cpu().numpy()
+    assert np.all(np.abs(gt - ot) <= 2 * np.spacing(np.abs(ot))), float(np.max(np.abs(gt - ot) / np.maximum(np.spacing(np.abs(ot)), 1e-30)))
     # filter: feed the GPU filter and the oracle the SAME decoded tensors -> identical anchors
     for thr, M in ((0.5, 100), (0.56, 17)):
         det = s.filter(boxes, cls, rot, trans, hand, score_threshold=thr, nms_threshold=0.5, max_detections=M)
@@ -256,12 +287,11 @@ def test_module_dropin_and_pipeline(api):
 
 
 @pytest.mark.parametrize("env", [{"HEP_MBF": "all"}, {"HEP_MBF": "none", "HEP_DWLDS": "0"}, {"HEP_DWLDS": "1", "HEP_MBF": "none"},
-                                 {"HEP_HEAD": "fused"}, {"HEP_LANES": "2"}, {"HEP_CHAIN": "0"}, {"HEP_PWG": "0", "HEP_PW_MT2": "0"}, {"HEP_TOWER": "0"},
-                                 {"HEP_TOWER": "0", "HEP_STREAM": "1"}])
+                                 {"HEP_LANES": "2"}, {"HEP_CHAIN": "0"}, {"HEP_PWG": "0", "HEP_PW_MT2": "0"}, {"HEP_TOWER": "0"}])
 def test_alternative_plans_keep_parity(api, env, monkeypatch):
     """The planner picks between implementations by measurement (fused MBConv front vs expand+depthwise,
-    fused heads vs per-layer vs streaming, node chains, LDS depthwise, batch lanes); every alternative must
-    produce the same numbers."""
+    tower kernel vs tiled sepconv for the heads, node chains, LDS depthwise, batch lanes); every alternative
+    must produce the same numbers."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     phi, size, batch = 0, 256, 3
@@ -280,7 +310,8 @@ def test_alternative_plans_keep_parity(api, env, monkeypatch):
 
 
 def test_inflight_pool_matches_single_session():
-    """Four batches in flight on four streams give bit-identical results to one session run serially."""
+    """Batches in flight on several streams give bit-identical results to one session run serially, also
+    when the consumer is slow (submit() used to hand back buffers it was already overwriting)."""
     import torch
     from hmd_ego_pose_amd import InflightPool
     from hmd_ego_pose_amd.model import Session
@@ -292,12 +323,14 @@ def test_inflight_pool_matches_single_session():
     cam = torch.tensor([[480, 480, 128, 128, 1000, 1.0]] * B, device="cuda")
     g = torch.Generator(device="cuda"); g.manual_seed(3)
     batches = [torch.randn(B if i % 2 == 0 else B - 1, 3, S, S, device="cuda", generator=g) for i in range(7)]
+    # a SLOW reader: .cpu() of every tensor (58 MB of hand rows per batch) while the other slots are in flight;
+    # a returned result must not be written again before the next submit()
     got = []
     for x in batches:
         r = pool.submit(x, cam[:x.shape[0]])
         if r is not None:
-            got.append({k: v.clone() for k, v in r.items()})
-    got += [{k: v.clone() for k, v in r.items()} for r in pool.drain()]
+            got.append({k: v.cpu() for k, v in sorted(r.items(), key=lambda kv: -kv[1].numel())})
+    got += [{k: v.cpu() for k, v in r.items()} for r in pool.drain()]
     assert len(got) == len(batches)
     for x, r in zip(batches, got):
         _, reg, cls, rot, trn, hand = ref.forward(x, want_features=False)
@@ -305,7 +338,7 @@ def test_inflight_pool_matches_single_session():
         torch.cuda.synchronize()
         for k, t in (("regression", reg), ("classification", cls), ("rotation", rot), ("translation_raw", trn), ("hand", hand),
                      ("boxes", boxes), ("translation", trans)):
-            assert r[k].shape == t.shape and torch.equal(r[k], t), k
+            assert r[k].shape == t.shape and torch.equal(r[k], t.cpu()), k
     pool.close(); ref.close()
 
 
@@ -364,3 +397,105 @@ def test_host_api_is_reentrant_from_threads(api):
         for a_, b_, c_ in zip(want[i], got[i], got[len(frames) + i]):
             assert np.array_equal(a_, b_) and np.array_equal(a_, c_), i
     for h in handles: h.close()
+
+
+def test_host_decode_and_filter_are_serialised_with_run(api):
+    """hep_run, hep_decode and hep_filter re-entered concurrently on ONE handle (the C# callbacks call all three
+    from worker threads): every caller gets the result of ITS inputs.  The host variants hold the handle's mutex
+    from staging to the final synchronise and stage in buffers of their own, never in the forward's outputs."""
+    import threading
+    capi = api["capi"]
+    lib = capi.lib()
+    phi, size = 0, 256
+    sd = api["sd"](phi, 3)
+    s = api["Session"](sd, phi, size, 1, "fp32")
+    N = s.num_anchors
+    frames = [seeded_input((1, 3, size, size), 40 + i) for i in range(4)]
+    cams = [np.array([[480 + 7 * i, 480 + 3 * i, 128, 128, 1000, 1.0]], np.float32) for i in range(4)]
+
+    def run(x):
+        outs = [np.empty((1, N, k), np.float32) for k in (4, 1, 3, 3, 63)]
+        capi.check(lib.hep_run(s.handle, x.ctypes.data, 1, None, *[o.ctypes.data for o in outs]))
+        return outs
+
+    def decode(outs, cam):
+        b, t = np.empty((1, N, 4), np.float32), np.empty((1, N, 3), np.float32)
+        capi.check(lib.hep_decode(s.handle, outs[0].ctypes.data, outs[3].ctypes.data, cam.ctypes.data, 1, b.ctypes.data, t.ctypes.data))
+        return b, t
+
+    def filt(outs, b, t):
+        M = 50
+        d = [np.empty((1, M, 4), np.float32), np.empty((1, M), np.float32), np.empty((1, M), np.int32), np.empty((1, M, 3), np.float32),
+             np.empty((1, M, 3), np.float32), np.empty((1, M, 63), np.float32), np.empty((1, M), np.int32), np.empty((1,), np.int32)]
+        capi.check(lib.hep_filter(s.handle, b.ctypes.data, outs[1].ctypes.data, outs[2].ctypes.data, t.ctypes.data, outs[4].ctypes.data, 1,
+                                  0.5, 0.5, M, *[a.ctypes.data for a in d]))
+        return d
+
+    want = []
+    for f, c in zip(frames, cams):                 # serial reference
+        o = run(f); b, t = decode(o, c); want.append((o, b, t, filt(o, b, t)))
+    got = [None] * len(frames)
+    errs = []
+
+    def worker(i):
+        try:
+            for _ in range(3):
+                o = run(frames[i]); b, t = decode(o, cams[i]); got[i] = (o, b, t, filt(o, b, t))
+        except Exception as e:      # pragma: no cover
+            errs.append(repr(e))
+
+    def decoder(i):                  # threads that only decode / filter somebody's serial results, interleaving with the runs
+        try:
+            for _ in range(6):
+                b, t = decode(want[i][0], cams[i])
+                assert np.array_equal(b, want[i][1]) and np.array_equal(t, want[i][2])
+                d = filt(want[i][0], want[i][1], want[i][2])
+                assert all(np.array_equal(u, v) for u, v in zip(d, want[i][3]))
+        except Exception as e:      # pragma: no cover
+            errs.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(len(frames))] + [threading.Thread(target=decoder, args=(i,)) for i in range(len(frames))]
+    for t in threads: t.start()
+    for t in threads: t.join()
+    assert not errs, errs
+    for i in range(len(frames)):
+        for u, v in zip(want[i][0], got[i][0]):
+            assert np.array_equal(u, v), i
+        assert np.array_equal(want[i][1], got[i][1]) and np.array_equal(want[i][2], got[i][2])
+        assert all(np.array_equal(u, v) for u, v in zip(want[i][3], got[i][3]))
+    # a decode with host inputs must not clobber the handle's own last outputs (NULL inputs read them)
+    o = run(frames[0])
+    decode(want[1][0], cams[1])
+    b2, t2 = np.empty((1, N, 4), np.float32), np.empty((1, N, 3), np.float32)
+    capi.check(lib.hep_decode(s.handle, None, None, cams[0].ctypes.data, 1, b2.ctypes.data, t2.ctypes.data))
+    assert np.array_equal(b2, want[0][1]) and np.array_equal(t2, want[0][2])
+    s.close()
+
+
+def test_create_from_pack_file_and_bad_arguments(api, tmp_path):
+    """hep_create(path) (what the C# host calls with model.hepw): same numbers as the in-memory constructor; missing
+    file, wrong phi for the pack and out-of-range batch in hep_debug_tensor are refused with a message."""
+    from hmd_ego_pose_amd import save_pack
+    capi = api["capi"]
+    lib = capi.lib()
+    phi, size = 0, 256
+    sd = api["sd"](phi, 6)
+    path = str(tmp_path / "model.hepw")
+    save_pack(sd, path)
+    h = ctypes.c_void_p()
+    capi.check(lib.hep_create(path.encode(), phi, size, 2, capi.HEP_F32, 0, 0, ctypes.byref(h)))
+    x = seeded_input((2, 3, size, size), 8)
+    N = lib.hep_num_anchors(h)
+    outs = [np.empty((2, N, k), np.float32) for k in (4, 1, 3, 3, 63)]
+    capi.check(lib.hep_run(h, x.ctypes.data, 2, None, *[o.ctypes.data for o in outs]))
+    s = api["Session"](sd, phi, size, 2, "fp32")
+    ref = s.forward(torch.from_numpy(x).cuda())
+    for o, r in zip(outs, ref[1:]):
+        assert np.array_equal(o, r.cpu().numpy())
+    buf = np.empty(16, np.float32)
+    assert lib.hep_debug_tensor(h, b"stem", 3, buf.ctypes.data, buf.size) == -4 and b"max_batch" in lib.hep_last_error()
+    lib.hep_destroy(h)
+    s.close()
+    h2 = ctypes.c_void_p()
+    assert lib.hep_create(str(tmp_path / "nope.hepw").encode(), phi, size, 1, capi.HEP_F32, 0, 0, ctypes.byref(h2)) == -2
+    assert lib.hep_create(path.encode(), 3, 512, 1, capi.HEP_F32, 0, 0, ctypes.byref(h2)) == -2 and b"weight pack" in lib.hep_last_error()

@@ -108,3 +108,42 @@ def test_module_state_dict_contract_and_cpu_refusal():
         m(torch.zeros(1, 3, 256, 256))
     with pytest.raises(ValueError, match="iter"):
         HMDEgoPose({"iter": 1}, compound_coef=0)
+
+
+def test_pack_weights_tool_roundtrip(tmp_path):
+    """tools/pack_weights.py: a `model.module.`-prefixed .pth checkpoint (what evaluate.py:102-116 loads) -> HEPW pack
+    holding the reference's tensors by their own names; a wrong phi is refused."""
+    import subprocess
+    import sys
+    sd = seeded_state_dict(0, 5)
+    ckpt = tmp_path / "ckpt.pth"
+    torch.save({("model.module." + k): v for k, v in sd.items()}, ckpt)
+    out = tmp_path / "m.hepw"
+    tool = os.path.join(REPO, "tools", "pack_weights.py")
+    r = subprocess.run([sys.executable, tool, str(ckpt), str(out), "--phi", "0"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    back = load_pack(out.read_bytes())
+    assert len(back) == len([k for k in sd if not k.endswith("num_batches_tracked")])
+    for k in ("backbone_net.model._blocks.7._se_reduce.conv.weight", "bifpn.2.p4_w2", "translation_net.initial_translation_z.pointwise_conv.conv.bias"):
+        assert np.array_equal(back[k], sd[k].numpy())
+    r = subprocess.run([sys.executable, tool, str(ckpt), str(out), "--phi", "3"], capture_output=True, text=True)
+    assert r.returncode != 0 and "does not match phi=3" in (r.stderr + r.stdout)
+
+
+def test_corrupt_pack_is_refused_without_reading_out_of_bounds():
+    """HEPW parser: offsets / sizes that wrap around 2^64, dims whose product overflows and tensors overlapping the
+    header are rejected (hep_create_from_memory parses the pack before it looks for a device)."""
+    import struct
+    l = _capi.lib()
+
+    def pack(dims, off, nb, total=4096):
+        name = b"t"
+        blob = b"HEPW" + struct.pack("<II", 1, 1) + struct.pack("<H", len(name)) + name + bytes([len(dims)])
+        blob += b"".join(struct.pack("<I", d) for d in dims) + struct.pack("<QQ", off, nb)
+        return blob + b"\0" * (total - len(blob))
+
+    for dims, off, nb in (([2], 2 ** 64 - 4, 8), ([2 ** 31, 2 ** 31, 4], 64, 0), ([2], 4, 8), ([1024], 64, 4096 * 4), ([2], 66, 8)):
+        blob = pack(dims, off, nb)
+        h = ctypes.c_void_p()
+        rc = l.hep_create_from_memory(blob, len(blob), 0, 256, 1, _capi.HEP_F32, 0, 0, ctypes.byref(h))
+        assert rc == -2 and b"weight pack" in l.hep_last_error(), (dims, off, nb, rc, l.hep_last_error())

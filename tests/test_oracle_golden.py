@@ -62,3 +62,29 @@ def test_network_forward_matches_reference(tag):
         check_digest(f"boxes_cam{ci}", boxes, info[f"boxes_cam{ci}"], gold[f"boxes_cam{ci}"], st, atol=1e-4, rtol=1e-5)
         check_digest(f"translation_cam{ci}", trans, info[f"translation_cam{ci}"], gold[f"translation_cam{ci}"], st,
                      atol=1e-3, rtol=1e-5)
+
+
+@pytest.mark.parametrize("tag", ["phi0_s256_b2_seed0", "phi3_s512_b1_seed0"])
+def test_storage_emulating_oracle_is_the_same_network(tag):
+    """oracle.forward_emulated restates the network with BN folded and explicit rounding hooks (the gate for the
+    bf16 / fp8 device sessions).  With identity hooks it must be the golden-pinned ``forward`` up to fp32
+    summation order; with the bf16 hooks it must show the drift bf16 storage causes (2-5 % mean relative on the
+    seeded weights) - neither zero (hooks not applied) nor large (a folding bug)."""
+    phi, size, batch, seed, kind = CASES[tag]
+    sd = seeded_state_dict(phi, seed)
+    x = torch.from_numpy(seeded_input((batch, 3, size, size), seed, kind))
+    tr_ref, tr_id = {}, {}
+    ref = R.forward(sd, x, phi, tr_ref)
+    idn = R.forward_emulated(sd, x, phi, tr_id, q_act=None, q_w=None)
+    for a, b in zip(ref[1:], idn[1:]):
+        assert (a - b).abs().max().item() <= 2e-5 * max(1.0, a.abs().max().item())
+    for k in tr_id:
+        assert (tr_ref[k] - tr_id[k]).abs().max().item() <= 2e-5 * max(1.0, tr_ref[k].abs().max().item()), k
+    emu = R.forward_emulated(sd, x, phi)
+    for name, a, b in zip(("regression", "classification", "rotation", "translation_raw", "hand"), ref[1:], emu[1:]):
+        rel = (a - b).abs().mean().item() / a.abs().mean().item()
+        assert 1e-3 < rel < 0.08, (name, rel)
+    # the hooks round to bf16 exactly: every stored activation is representable
+    # (8 significant bits, ties to even: 1 + 2^-8 is a tie -> 1.0, 1 + 2^-7 + 2^-8 is a tie -> 1 + 2^-6)
+    t = R.q_bf16(torch.tensor([1.0 + 2 ** -9, 1.0 + 2 ** -8, 1.0 + 2 ** -8 + 2 ** -9, 1.0 + 2 ** -7 + 2 ** -8, -3.14159]))
+    assert t.tolist() == [1.0, 1.0, 1.0078125, 1.015625, -3.140625]

@@ -19,7 +19,7 @@ def main():
     a = ap.parse_args()
     import torch
     from hmd_ego_pose_amd import param_spec, save_pack, strip_checkpoint_prefix
-    state = strip_checkpoint_prefix(torch.load(a.checkpoint, map_location="cpu"))
+    state = strip_checkpoint_prefix(torch.load(a.checkpoint, map_location="cpu", weights_only=True))
     want = dict(param_spec(a.phi))
     missing = [k for k in want if k not in state and not k.endswith("num_batches_tracked")]
     wrong = [k for k in want if k in state and tuple(state[k].shape) != want[k]]
