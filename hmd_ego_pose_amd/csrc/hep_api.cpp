@@ -469,11 +469,11 @@ int hep_kernel_symbol(const hep_handle* h, int i, const char** symbol) {
   char tmp[128];
   switch (o.kind) {
     case OP_STEM: snprintf(tmp, sizeof tmp, "stem_kernel<%s>", t); break;
-    case OP_PW: snprintf(tmp, sizeof tmp, "pw_gemm_kernel<%s, %d, %d, %d, %d>", t, o.pw.MT, o.pw.NT, o.pw.mode, o.pw.act == ACT_SWISH ? 1 : 0); break;
+    case OP_PW: snprintf(tmp, sizeof tmp, "pw_gemm_kernel<%s, %d, %d, %d, %d, %d>", t, o.pw.MT, o.pw.NT, o.pw.mode, o.pw.act == ACT_SWISH ? 1 : 0, pw_se_variant(o.pw)); break;
     case OP_DW: snprintf(tmp, sizeof tmp, "dw_kernel<%s, %d, %d, %d>", t, o.dw.k, o.dw.s, o.dw.TW); break;
     case OP_POOL: snprintf(tmp, sizeof tmp, "pool_kernel<%s>", t); break;
     case OP_PWG: snprintf(tmp, sizeof tmp, "pw_group_kernel<%s>", t); break;
-    case OP_MBF: snprintf(tmp, sizeof tmp, "mbf_kernel<%s, %d, %d>", t, o.mbf.k, o.mbf.s); break;
+    case OP_MBF: snprintf(tmp, sizeof tmp, "mbf_kernel<%s, %d, %d, %d>", t, o.mbf.k, o.mbf.s, o.mbf.ts); break;
     default: if (o.sep.direct) snprintf(tmp, sizeof tmp, "tower_kernel<%s, %d, %s>", t, o.sep.C, o.sep.direct == 2 ? "true" : "false");
              else snprintf(tmp, sizeof tmp, "sep_kernel<%s, %d>", t, o.sep.chain ? 2 : (o.sep.nseg == 1 ? 0 : 1));
              break;

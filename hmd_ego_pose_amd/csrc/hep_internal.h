@@ -28,7 +28,7 @@ struct PwArgs {
   // hpart[b][row][sqp] = per-workgroup partial products of the reduce FC with its channel sums; the
   // prologue of this kernel finishes hidden = swish(sum_rows * inv_hw + br) and the expand FC
   // scale[k] = sigmoid(we[k,:] . hidden + be[k]) for the images its rows belong to (k_pw.hip)
-  const float* hpart; const float* se_br; const float* se_we /*[K][sqp]*/; const float* se_be;
+  const float* hpart; const float* se_br; const void* se_we /*[K][sqp], session dtype*/; const float* se_be;
   int se_rows, sq, sqp, se_nimg; float inv_hw;
   const void* res;     // [M,N] residual (nullable)
   void* out;
@@ -66,7 +66,9 @@ struct MbfArgs {
   int sq, sqp;
   int B, H, W, Cin, Cexp, Ho, Wo, k, s, pad_t, pad_l, has_expand, bf16;
   int CC;              // expanded channels per workgroup (8 * power of two)
+  int ts;              // output tile side: 8, or 16 (stride-1 layers on maps >= 16x16; k_mbf.hip)
   size_t off_e, off_we, off_w, lds_bytes;
+  int trace;           // profiling builds (-DHEP_MBF_TRACE): this launch writes its phase time stamps
 };
 
 // ---- 3x3 s2 max-pool, TF-SAME with ZERO padding (utils_extra.py:72-86) ----
@@ -124,12 +126,13 @@ struct FilterArgs {
 
 void launch_stem(const StemArgs&, hipStream_t);
 void launch_pw(const PwArgs&, hipStream_t);
+int pw_se_variant(const PwArgs&);   // 0 none, 1 shallow, 2 deep (template parameter of pw_gemm_kernel)
 void launch_pwg(const PwgArgs&, hipStream_t);
 void launch_dw(const DwArgs&, hipStream_t);
 void launch_pool(const PoolArgs&, hipStream_t);
 void launch_mbf(const MbfArgs&, hipStream_t);
-size_t mbf_lds_layout(int Cin, int CC, int k, int s, int bf16, int has_expand, int max_inside, MbfArgs* a);
-int mbf_max_inside(int H, int W, int k, int s, int pad_t, int pad_l);
+size_t mbf_lds_layout(int Cin, int CC, int k, int s, int bf16, int has_expand, int max_inside, int ts, MbfArgs* a);
+int mbf_max_inside(int H, int W, int k, int s, int pad_t, int pad_l, int ts);
 int mbf_prepare(void);
 void launch_sep(const SepArgs&, hipStream_t);
 void launch_tower(const SepArgs&, hipStream_t);

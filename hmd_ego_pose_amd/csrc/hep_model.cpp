@@ -291,7 +291,7 @@ struct Planner {
       const int rows_wg = o.pw.mode == 0 ? 64 * o.pw.MT : 16 * o.pw.MT;
       o.pw.se_nimg = HW % rows_wg == 0 ? 1 : (rows_wg + HW - 1) / HW + 1;
       o.act_bytes_per_image += ((double)se->rows * se->sqp + se->sq) * 4;
-      o.weight_bytes += ((double)K * se->sq + K + se->sq) * 4;
+      o.weight_bytes += (double)K * se->sq * es() + ((double)K + se->sq) * 4;
       o.flops_per_image += 2.0 * K * se->sq;
     }
     return out_t;
@@ -354,7 +354,16 @@ struct Planner {
 
     // fused front (expand -> LDS -> depthwise, k_mbf.hip) whenever its LDS tiles fit; the expanded
     // tensor then never reaches HBM.  HEP_NO_MBF=1 forces the two-kernel path (A/B measurements).
-    const int max_in = mbf_max_inside(Hin, Win, b.k, b.stride, pt, pl);   // rows of the compact input tile in LDS
+    // output tile side of the fused front: 16 on the stride-1 layers of 16x16 / 32x32 maps (the whole 16x16 map per
+    // workgroup: no halo re-expansion, a quarter of the workgroups and of their fixed staging / drain latency), else 8.
+    // HEP_MBF_TS=8 forces the small tile (A/B measurements, parity test of the alternative plan).
+    int ts = (b.stride == 1 && b.expand && Ho >= 16 && Ho <= 32) ? 16 : 8;
+    if (const char* e = getenv("HEP_MBF_TS")) if (atoi(e) == 8) ts = 8;
+    int max_in = mbf_max_inside(Hin, Win, b.k, b.stride, pt, pl, ts);   // rows of the compact input tile in LDS
+    if (ts == 16 && mbf_lds_layout(b.cin, 64, b.k, b.stride, s->dtype, b.expand, max_in, ts, nullptr) > 159 * 1024 &&
+        mbf_lds_layout(b.cin, 32, b.k, b.stride, s->dtype, b.expand, max_in, ts, nullptr) > 159 * 1024) {
+      ts = 8; max_in = mbf_max_inside(Hin, Win, b.k, b.stride, pt, pl, ts);
+    }
     int CC = 0;
     // Measured on MI355X at bs16 (profiles/README.md): the fused kernel beats expand+depthwise on input
     // maps up to 32x32 (it expands only the tile pixels inside the image, so on the 8x8 maps the halo costs
@@ -364,13 +373,13 @@ struct Planner {
     const bool want = mode ? !strcmp(mode, "all") : Hin <= 32;
     if (want && !(mode && !strcmp(mode, "none")))
       for (int cand : {64, 32, 16})
-        if (mbf_lds_layout(b.cin, std::min(cand, b.expand ? cand : b.cexp), b.k, b.stride, s->dtype, b.expand, max_in, nullptr) <= 159 * 1024) { CC = cand; break; }
-    // squeeze-excite weights: reduce FC [sq][Cexp] for the front kernel; bias, expand FC [Cexp][sqp] (rows
-    // padded to a multiple of 4 with zeros) and its bias for the project GEMM's prologue
+        if (mbf_lds_layout(b.cin, std::min(cand, b.expand ? cand : b.cexp), b.k, b.stride, s->dtype, b.expand, max_in, ts, nullptr) <= 159 * 1024) { CC = cand; break; }
+    // squeeze-excite weights: reduce FC [sq][Cexp] (fp32) for the front kernel; bias, expand FC [Cexp][sqp] (session
+    // dtype, rows padded with zeros) and its bias for the project GEMM's prologue
     const PackTensor *wr = get(p + "._se_reduce.conv.weight", {b.se, b.cexp, 1, 1}), *br = get(p + "._se_reduce.conv.bias", {b.se}),
                      *we = get(p + "._se_expand.conv.weight", {b.cexp, b.se, 1, 1}), *be = get(p + "._se_expand.conv.bias", {b.cexp});
     if (!ok) return -1;
-    const int sqp = (b.se + 3) & ~3;
+    const int sqp = (b.se + 7) & ~7;          // one 16-byte vector of the expand-FC weights = 8 (bf16) / 4 (fp32) hidden units
     if (sqp > 256) { *err = "squeeze-excite width above 256 is not supported"; ok = false; return -1; }
     const size_t wr_off = wb.put_f32(std::vector<float>(wr->data, wr->data + wr->count));
     SeSpec se; se.sq = b.se; se.sqp = sqp; se.inv_hw = 1.0f / (float)(Ho * Wo);
@@ -378,13 +387,13 @@ struct Planner {
     {
       std::vector<float> wep((size_t)b.cexp * sqp, 0.f);
       for (int c = 0; c < b.cexp; c++) for (int j = 0; j < b.se; j++) wep[(size_t)c * sqp + j] = we->data[(size_t)c * b.se + j];
-      se.we = wb.put_f32(wep);
+      se.we = wb.put_typed(wep);              // session dtype: half the bytes of the project prologue in bf16 sessions
     }
     se.be = wb.put_f32(std::vector<float>(be->data, be->data + be->count));
     int part_t, nblk;
     if (CC) {
       if (!b.expand) CC = std::min(CC, b.cexp);
-      nblk = ((Ho + 7) / 8) * ((Wo + 7) / 8) * ((b.cexp + CC - 1) / CC);      // one row per workgroup
+      nblk = ((Ho + ts - 1) / ts) * ((Wo + ts - 1) / ts) * ((b.cexp + CC - 1) / CC);      // one row per workgroup
       snprintf(nm, sizeof nm, "b%d.se_hpart", i);
       part_t = tensor(nm, 1, nblk, sqp, true);
       snprintf(nm, sizeof nm, "b%d.front", i);
@@ -392,8 +401,8 @@ struct Planner {
       Op& o = s->ops[op];
       MbfArgs& m = o.mbf; memset(&m, 0, sizeof m);
       m.H = Hin; m.W = Win; m.Cin = b.cin; m.Cexp = b.cexp; m.Ho = Ho; m.Wo = Wo; m.k = b.k; m.s = b.stride;
-      m.pad_t = pt; m.pad_l = pl; m.has_expand = b.expand; m.bf16 = s->dtype; m.CC = CC; m.sq = b.se; m.sqp = sqp;
-      mbf_lds_layout(b.cin, CC, b.k, b.stride, s->dtype, b.expand, max_in, &m);
+      m.pad_t = pt; m.pad_l = pl; m.has_expand = b.expand; m.bf16 = s->dtype; m.CC = CC; m.sq = b.se; m.sqp = sqp; m.ts = ts;
+      mbf_lds_layout(b.cin, CC, b.k, b.stride, s->dtype, b.expand, max_in, ts, &m);
       wref(op, F_MBF_WR, wr_off);
       if (b.expand) {
         const PackTensor* w = get(p + "._expand_conv.conv.weight", {b.cexp, b.cin, 1, 1});
@@ -424,7 +433,8 @@ struct Planner {
       //  27.2 us from global memory - 25 taps per output re-read too much through L1)
       const bool lds_dw = dl ? atoi(dl) != 0 : (Hin <= 8 || (b.k == 5 && Hin <= 64));
       const int ccl = std::min(64, b.cexp);
-      if (lds_dw && mbf_lds_layout(b.cexp, ccl, b.k, b.stride, s->dtype, 0, max_in, nullptr) <= 159 * 1024) {
+      const int max_in8 = mbf_max_inside(Hin, Win, b.k, b.stride, pt, pl, 8);
+      if (lds_dw && mbf_lds_layout(b.cexp, ccl, b.k, b.stride, s->dtype, 0, max_in8, 8, nullptr) <= 159 * 1024) {
         nblk = ((Ho + 7) / 8) * ((Wo + 7) / 8) * ((b.cexp + ccl - 1) / ccl);
         snprintf(nm, sizeof nm, "b%d.se_hpart", i);
         part_t = tensor(nm, 1, nblk, sqp, true);
@@ -433,8 +443,8 @@ struct Planner {
         Op& o = s->ops[op];
         MbfArgs& m = o.mbf; memset(&m, 0, sizeof m);
         m.H = Hin; m.W = Win; m.Cin = b.cexp; m.Cexp = b.cexp; m.Ho = Ho; m.Wo = Wo; m.k = b.k; m.s = b.stride;
-        m.pad_t = pt; m.pad_l = pl; m.has_expand = 0; m.bf16 = s->dtype; m.CC = ccl; m.sq = b.se; m.sqp = sqp;
-        mbf_lds_layout(b.cexp, ccl, b.k, b.stride, s->dtype, 0, max_in, &m);
+        m.pad_t = pt; m.pad_l = pl; m.has_expand = 0; m.bf16 = s->dtype; m.CC = ccl; m.sq = b.se; m.sqp = sqp; m.ts = 8;
+        mbf_lds_layout(b.cexp, ccl, b.k, b.stride, s->dtype, 0, max_in8, 8, &m);
         wref(op, F_MBF_WR, wr_off);
         wref(op, F_MBF_WDW, wb.put_f32(wdw)); wref(op, F_MBF_BDW, wb.put_f32(bn1.shift));
         tref(op, F_MBF_IN, x, false); tref(op, F_MBF_OUT, dw_t, true); tref(op, F_MBF_PART, part_t, true);
@@ -844,7 +854,7 @@ int build_session(Session* s, const Pack& pack, std::string* err) {
         case F_PW_B: o.pw.bias = (const float*)ptr; break;
         case F_PW_HPART: o.pw.hpart = (const float*)ptr; break;
         case F_PW_SEBR: o.pw.se_br = (const float*)ptr; break;
-        case F_PW_SEWE: o.pw.se_we = (const float*)ptr; break;
+        case F_PW_SEWE: o.pw.se_we = ptr; break;
         case F_PW_SEBE: o.pw.se_be = (const float*)ptr; break;
         case F_PW_RES: o.pw.res = ptr; break;
         case F_PW_OUT: o.pw.out = ptr; break;

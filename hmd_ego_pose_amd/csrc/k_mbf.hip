@@ -20,6 +20,7 @@
 //            reduce weights -> hpart[b][workgroup][j]   (no atomics; the project GEMM finishes the SE)
 // Blocks without an expand conv (first block of the net) skip phase B: the input tile IS the
 // depthwise input.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <algorithm>
@@ -29,8 +30,10 @@
 #include "hep_dev.h"
 #include "hep_internal.h"
 
-#define MBF_THREADS 512
-#define MBF_WAVES 8
+// Tile side TS: 8 (512 threads, two workgroups per CU) for the stride-2 layers and the 8x8 maps, 16 (1024
+// threads) for the stride-1 layers on 16x16 / 32x32 maps: there an 8x8 tile re-expands its k x k halo (2.25x the
+// pixels for k = 5) and every one of the 4x more workgroups pays the fixed staging / drain latency - the 16x16
+// tile is the whole 16x16 map (no halo work at all) and a quarter of the 32x32 one.
 
 // Optional per-wave timeline (make EXTRA=-DHEP_MBF_TRACE): s_memrealtime (100 MHz) stamps at the phase
 // boundaries of the LAST mbf launch, read back with hep_dbg_mbf_trace() - profiling builds only.
@@ -44,13 +47,13 @@ __device__ unsigned long long* g_mbf_trace = nullptr;
 // exact x / d for x * d < 2^32 with rcp = floor(2^32 / d) + 1
 __device__ __forceinline__ int fast_div_u(int x, uint32_t rcp) { return (int)__umulhi((uint32_t)x, rcp); }
 
-template <bool BF16, int KS, int S>
-__global__ __launch_bounds__(MBF_THREADS) void mbf_kernel(MbfArgs a) {
+template <bool BF16, int KS, int S, int TS>
+__global__ __launch_bounds__(TS == 16 ? 1024 : 512) void mbf_kernel(MbfArgs a) {
+  constexpr int MBF_THREADS = TS == 16 ? 1024 : 512, MBF_WAVES = MBF_THREADS / 64;
   typedef Vec8<BF16> V;
   typedef typename V::elem T;
   typedef typename std::conditional<BF16, u32x4, f32x4>::type raw_t;
   constexpr int KSTEP = BF16 ? 32 : 16, KLANE = BF16 ? 8 : 4, PAD = BF16 ? 8 : 4;
-  constexpr int TS = 8;                              // output tile side
   constexpr int PW = (TS - 1) * S + KS;              // input tile side
   constexpr int PIN = PW * PW;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -232,12 +235,15 @@ __global__ __launch_bounds__(MBF_THREADS) void mbf_kernel(MbfArgs a) {
   const int cgs = cc >> 3;
   int cgsh = 0; while ((1 << cgsh) < cgs) cgsh++;
   const int cgp = 1 << cgsh;
-  const int half = threadIdx.x >> 8, tl = threadIdx.x & 255;
+  // (TS 16: 128 pixel pairs x 8 channel groups = one item per lane, all tap rows, no hand-over)
+  constexpr bool SPLIT = TS == 8;
+  constexpr int HALF = SPLIT ? MBF_THREADS / 2 : MBF_THREADS;
+  const int half = SPLIT ? threadIdx.x / HALF : 0, tl = SPLIT ? threadIdx.x % HALF : threadIdx.x;
   const int cg = tl & (cgp - 1), pp = tl >> cgsh;                          // pixel pair 0 .. TS*TS/2 - 1
-  f32x4* xch = reinterpret_cast<f32x4*>(smem);                             // [4][256] float4: partial sums of waves 4-7
+  f32x4* xch = reinterpret_cast<f32x4*>(smem);                             // [4][HALF] float4: partial sums of the second half (SPLIT)
   float sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const bool item = cg < cgs && pp < TS * TS / 2;
-  constexpr int KH = (KS + 1) / 2;
+  constexpr int KH = SPLIT ? (KS + 1) / 2 : KS;
   float acc0[8], acc1[8];
   constexpr int NX = S + KS;
   const int py = pp / (TS / 2), px = (pp % (TS / 2)) * 2;
@@ -264,16 +270,18 @@ __global__ __launch_bounds__(MBF_THREADS) void mbf_kernel(MbfArgs a) {
         }
       }
     }
-    if (half) {
-      xch[0 * 256 + tl] = (f32x4){acc0[0], acc0[1], acc0[2], acc0[3]}; xch[1 * 256 + tl] = (f32x4){acc0[4], acc0[5], acc0[6], acc0[7]};
-      xch[2 * 256 + tl] = (f32x4){acc1[0], acc1[1], acc1[2], acc1[3]}; xch[3 * 256 + tl] = (f32x4){acc1[4], acc1[5], acc1[6], acc1[7]};
+    if (SPLIT && half) {
+      xch[0 * HALF + tl] = (f32x4){acc0[0], acc0[1], acc0[2], acc0[3]}; xch[1 * HALF + tl] = (f32x4){acc0[4], acc0[5], acc0[6], acc0[7]};
+      xch[2 * HALF + tl] = (f32x4){acc1[0], acc1[1], acc1[2], acc1[3]}; xch[3 * HALF + tl] = (f32x4){acc1[4], acc1[5], acc1[6], acc1[7]};
     }
   }
   __syncthreads();
   if (item && !half) {
-    const f32x4 p0 = xch[tl], p1 = xch[256 + tl], p2 = xch[512 + tl], p3 = xch[768 + tl];
+    if constexpr (SPLIT) {
+      const f32x4 p0 = xch[tl], p1 = xch[HALF + tl], p2 = xch[2 * HALF + tl], p3 = xch[3 * HALF + tl];
 #pragma unroll
-    for (int c = 0; c < 4; c++) { acc0[c] += p0[c]; acc0[4 + c] += p1[c]; acc1[c] += p2[c]; acc1[4 + c] += p3[c]; }
+      for (int c = 0; c < 4; c++) { acc0[c] += p0[c]; acc0[4 + c] += p1[c]; acc1[c] += p2[c]; acc1[4 + c] += p3[c]; }
+    }
     const int oy = oy0 + py, ox = ox0 + px;
     if (oy < a.Ho && ox < a.Wo) {
       float v[8];
@@ -294,10 +302,11 @@ __global__ __launch_bounds__(MBF_THREADS) void mbf_kernel(MbfArgs a) {
   //        hpart[b][workgroup][j] = sum_{c in chunk} wr[j][c0 + c] * (sum of this tile's outputs of channel c)
   //      and the project GEMM (k_pw.hip) adds the rows up, applies 1/HW, bias and swish and runs the
   //      expand FC in its prologue - no squeeze-excite launch.  Fixed order everywhere (wave butterfly,
-  //      the four depthwise waves added 0..3, lane butterfly): bit-reproducible, no atomics. ----
+  //      the depthwise waves added in order, lane butterfly): bit-reproducible, no atomics. ----
   if (a.hpart) {
-    float* ssum = reinterpret_cast<float*>(smem + a.off_e);               // [4][CC]: the expanded tile is dead
-    if (wave < 4) {
+    constexpr int NWC = HALF / 64;                                        // waves that produced outputs
+    float* ssum = reinterpret_cast<float*>(smem + a.off_e);               // [NWC][CC]: the expanded tile is dead
+    if (wave < NWC) {
       for (int off = cgp; off < 64; off <<= 1) {
 #pragma unroll
         for (int c = 0; c < 8; c++) sum[c] += __shfl_xor(sum[c], off, 64);
@@ -312,7 +321,7 @@ __global__ __launch_bounds__(MBF_THREADS) void mbf_kernel(MbfArgs a) {
     float cs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (ch < cc) {
 #pragma unroll
-      for (int w4 = 0; w4 < 4; w4++) {
+      for (int w4 = 0; w4 < NWC; w4++) {
         const f32x4* sp = reinterpret_cast<const f32x4*>(ssum + w4 * a.CC + ch);
         const f32x4 s0 = sp[0], s1 = sp[1];
 #pragma unroll
@@ -334,7 +343,7 @@ __global__ __launch_bounds__(MBF_THREADS) void mbf_kernel(MbfArgs a) {
   }
 #ifdef HEP_MBF_TRACE
   MSTAMP(6);
-  if (g_mbf_trace && lane == 0) {
+  if (g_mbf_trace && a.trace && lane == 0) {
     unsigned long long* o = g_mbf_trace + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * MBF_WAVES + wave) * 8;
     for (int i = 0; i < 7; i++) o[i] = stamps[i];
     o[7] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
@@ -354,13 +363,13 @@ extern "C" int hep_dbg_mbf_trace(unsigned long long* host, int max_waves, int en
 }
 #endif
 
-// rows of the compact input tile: the most in-image pixels any 8x8-output tile of an H x W map covers
-int mbf_max_inside(int H, int W, int k, int s, int pad_t, int pad_l) {
-  const int pw = (8 - 1) * s + k;
+// rows of the compact input tile: the most in-image pixels any ts x ts-output tile of an H x W map covers
+int mbf_max_inside(int H, int W, int k, int s, int pad_t, int pad_l, int ts) {
+  const int pw = (ts - 1) * s + k;
   auto span = [&](int n, int pad) {
     const int no = (n + s - 1) / s;                        // output size along this axis (SAME)
     int best = 0;
-    for (int t0 = 0; t0 < no; t0 += 8) {
+    for (int t0 = 0; t0 < no; t0 += ts) {
       const int i0 = t0 * s - pad, lo = std::max(0, -i0), hi = std::min(pw, n - i0);
       best = std::max(best, hi - lo);
     }
@@ -369,39 +378,54 @@ int mbf_max_inside(int H, int W, int k, int s, int pad_t, int pad_l) {
   return span(H, pad_t) * span(W, pad_l);
 }
 
-size_t mbf_lds_layout(int Cin, int CC, int k, int s, int bf16, int has_expand, int max_inside, MbfArgs* a) {
+int mbf_threads(int ts) { return ts == 16 ? 1024 : 512; }
+
+size_t mbf_lds_layout(int Cin, int CC, int k, int s, int bf16, int has_expand, int max_inside, int ts, MbfArgs* a) {
   const size_t es = bf16 ? 2 : 4, pad = bf16 ? 8 : 4;
-  const size_t pw = (size_t)(8 - 1) * s + k, pin = pw * pw;
+  const size_t pw = (size_t)(ts - 1) * s + k, pin = pw * pw;
   const size_t arows = (((size_t)std::min<int>(max_inside, (int)pin) + 31) / 32) * 32;   // phase B reads whole pairs of 16-row m-tiles
   size_t in_bytes = has_expand ? arows * (Cin + pad) * es : 0;
-  in_bytes = std::max(in_bytes, (size_t)MBF_THREADS * 9 * 4);            // phase D scratch lives there too
+  in_bytes = std::max(in_bytes, (size_t)mbf_threads(ts) * 9 * 4);        // the tap-row hand-over of phase C lives there too
   in_bytes = (in_bytes + 15) & ~(size_t)15;
-  const size_t e_bytes = (pin * (CC + pad) * es + 15) & ~(size_t)15;
+  const size_t e_bytes = (std::max(pin * (CC + pad) * es, (size_t)16 * CC * 4) + 15) & ~(size_t)15;   // (phase D: [<= 16][CC] channel sums)
   const size_t w_bytes = (size_t)(k * k + 2) * CC * 4;                    // depthwise weights + the two bias vectors
   const size_t we_bytes = has_expand ? (((size_t)CC * (Cin + pad) * es + 15) & ~(size_t)15) : 0;   // expand-weight chunk
   if (a) { a->off_e = in_bytes; a->off_we = in_bytes + e_bytes; a->off_w = a->off_we + we_bytes; a->lds_bytes = a->off_w + w_bytes; }
   return in_bytes + e_bytes + we_bytes + w_bytes;
 }
 
-template <bool BF16, int KS, int S>
+template <bool BF16, int KS, int S, int TS>
 static int prep_one() {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(mbf_kernel<BF16, KS, S>), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024) == hipSuccess ? 0 : -1;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(mbf_kernel<BF16, KS, S, TS>), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024) == hipSuccess ? 0 : -1;
 }
 int mbf_prepare(void) {
-  return prep_one<true, 3, 1>() | prep_one<true, 3, 2>() | prep_one<true, 5, 1>() | prep_one<true, 5, 2>() |
-         prep_one<false, 3, 1>() | prep_one<false, 3, 2>() | prep_one<false, 5, 1>() | prep_one<false, 5, 2>();
+  return prep_one<true, 3, 1, 8>() | prep_one<true, 3, 2, 8>() | prep_one<true, 5, 1, 8>() | prep_one<true, 5, 2, 8>() |
+         prep_one<false, 3, 1, 8>() | prep_one<false, 3, 2, 8>() | prep_one<false, 5, 1, 8>() | prep_one<false, 5, 2, 8>() |
+         prep_one<true, 3, 1, 16>() | prep_one<true, 5, 1, 16>() | prep_one<false, 3, 1, 16>() | prep_one<false, 5, 1, 16>();
 }
 
 template <bool BF16>
 static void launch_mbf_t(const MbfArgs& a, dim3 grid, hipStream_t s) {
-  if (a.k == 3 && a.s == 1) hipLaunchKernelGGL((mbf_kernel<BF16, 3, 1>), grid, dim3(MBF_THREADS), a.lds_bytes, s, a);
-  else if (a.k == 3 && a.s == 2) hipLaunchKernelGGL((mbf_kernel<BF16, 3, 2>), grid, dim3(MBF_THREADS), a.lds_bytes, s, a);
-  else if (a.k == 5 && a.s == 1) hipLaunchKernelGGL((mbf_kernel<BF16, 5, 1>), grid, dim3(MBF_THREADS), a.lds_bytes, s, a);
-  else hipLaunchKernelGGL((mbf_kernel<BF16, 5, 2>), grid, dim3(MBF_THREADS), a.lds_bytes, s, a);
+  if (a.ts == 16) {       // stride 1 only (the planner never asks for 16x16 tiles on a stride-2 layer)
+    if (a.k == 3) hipLaunchKernelGGL((mbf_kernel<BF16, 3, 1, 16>), grid, dim3(1024), a.lds_bytes, s, a);
+    else hipLaunchKernelGGL((mbf_kernel<BF16, 5, 1, 16>), grid, dim3(1024), a.lds_bytes, s, a);
+  }
+  else if (a.k == 3 && a.s == 1) hipLaunchKernelGGL((mbf_kernel<BF16, 3, 1, 8>), grid, dim3(512), a.lds_bytes, s, a);
+  else if (a.k == 3 && a.s == 2) hipLaunchKernelGGL((mbf_kernel<BF16, 3, 2, 8>), grid, dim3(512), a.lds_bytes, s, a);
+  else if (a.k == 5 && a.s == 1) hipLaunchKernelGGL((mbf_kernel<BF16, 5, 1, 8>), grid, dim3(512), a.lds_bytes, s, a);
+  else hipLaunchKernelGGL((mbf_kernel<BF16, 5, 2, 8>), grid, dim3(512), a.lds_bytes, s, a);
 }
 void launch_mbf(const MbfArgs& a_, hipStream_t s) {
-  const MbfArgs& a = a_;
-  const int tiles = ((a.Wo + 7) / 8) * ((a.Ho + 7) / 8), chunks = (a.Cexp + a.CC - 1) / a.CC;
+  MbfArgs a = a_;
+#ifdef HEP_MBF_TRACE
+  {   // profiling build: HEP_MBF_TRACE_SEL="Cexp,H" keeps the stamps of that layer only (default: every launch, last wins)
+    static const char* sel = getenv("HEP_MBF_TRACE_SEL");
+    int c = 0, h = 0;
+    if (sel) sscanf(sel, "%d,%d", &c, &h);
+    a.trace = !sel || (a.Cexp == c && a.H == h);
+  }
+#endif
+  const int tiles = ((a.Wo + a.ts - 1) / a.ts) * ((a.Ho + a.ts - 1) / a.ts), chunks = (a.Cexp + a.CC - 1) / a.CC;
   dim3 grid(tiles * chunks, a.B);
   if (a.bf16) launch_mbf_t<true>(a, grid, s); else launch_mbf_t<false>(a, grid, s);
 }

@@ -44,7 +44,10 @@ struct Step {
 
 // ACT (none | swish) is a template parameter: with a run-time activation the epilogue carried a scalar
 // branch per output element
-template <bool BF16, int MT, int NT, int MODE, int ACT>
+// SEV: squeeze-excite prologue variant - 0 none (expand / lateral convs), 1 one weight row x two vectors in flight
+// per lane (K <= 256: the project convs on the big maps, which need their occupancy), 2 five rows x six vectors
+// (deep K on the small maps).  A template parameter because the rows in flight set the kernel's register count.
+template <bool BF16, int MT, int NT, int MODE, int ACT, int SEV>
 __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
   typedef Vec8<BF16> V;
   typedef typename V::elem T;
@@ -71,18 +74,40 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
   }
 
   // ---- squeeze-excite prologue: scale_s[image - img0][k] for the images this workgroup's rows belong to ----
+  // A chain of dependent round trips if written naively (hpart rows -> hidden -> weight rows -> scale), and it
+  // sits in front of every project GEMM, so: the first batch of expand-FC weight rows (independent of the hidden
+  // vector) is put in flight BEFORE the hpart rows are fetched and reduced, RB rows x VB 16-byte vectors per lane
+  // at once (K = 1152, sq = 48 in bf16: everything in one batch, one round trip); the weights are in the session
+  // dtype (bf16 sessions: half the bytes; the products are accumulated in fp32).
   extern __shared__ __attribute__((aligned(16))) float se_s[];
-  const bool SE = a.hpart != nullptr;
+  constexpr bool SE = SEV != 0;
   int img0 = 0;
-  if (SE) {
+  if constexpr (SE) {
     constexpr int ROWS = MODE == 0 ? 64 * MT : 16 * MT;
+    constexpr int JV = BF16 ? 8 : 4;              // hidden units per 16-byte weight vector
+    constexpr int RB = SEV == 2 ? 5 : 1, VB = SEV == 2 ? 6 : 2;   // weight rows x vectors in flight per lane
     const int mfirst = mblk * ROWS, mlast = min(M, mfirst + ROWS) - 1;
     img0 = mfirst / a.HW;
     const int img1 = mlast / a.HW, sqp = a.sqp, sq = a.sq;
+    const int V = sqp / JV, R = (K + 255) >> 8;
+    const T* WE = reinterpret_cast<const T*>(a.se_we);
     float* hid_s = se_s + a.se_nimg * K;          // [sqp]
     float* red_s = hid_s + sqp;                   // [G][sqp] row sums of the G helper groups
     const int G = max(1, 256 / sqp);
     const int grp = threadIdx.x / sqp, j = threadIdx.x - grp * sqp;
+    raw_t wv[RB][VB];
+    auto issue = [&](int r0, int v0) {
+#pragma unroll
+      for (int rr = 0; rr < RB; rr++) {
+        const int k = ((r0 + rr) << 8) + threadIdx.x;
+#pragma unroll
+        for (int vv = 0; vv < VB; vv++) {
+          wv[rr][vv] = raw_t{};
+          if (k < K && v0 + vv < V) wv[rr][vv] = *reinterpret_cast<const raw_t*>(WE + (int64_t)k * sqp + (v0 + vv) * JV);
+        }
+      }
+    };
+    issue(0, 0);
     for (int img = img0; img <= img1; img++) {
       // hidden[j] = swish(inv_hw * sum_rows hpart[img][row][j] + br[j]): G groups each add every G-th row,
       // then the groups are added up - fixed order
@@ -107,16 +132,41 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
         hid_s[threadIdx.x] = h;                  // padding entries are exact zeros
       }
       __syncthreads();
-      // expand FC + sigmoid: one weight row we[k][0..sqp) per thread and k
+      // expand FC + sigmoid: lane t owns the weight rows k = t, t + 256, ...
       float* sc = se_s + (img - img0) * K;
-      for (int k = threadIdx.x; k < K; k += 256) {
-        const f32x4* wp = reinterpret_cast<const f32x4*>(a.se_we + (int64_t)k * sqp);
-        float e0 = a.se_be[k], e1 = 0.f, e2 = 0.f, e3 = 0.f;
-        for (int j4 = 0; j4 < sqp; j4 += 4) {
-          const f32x4 w = wp[j4 >> 2], h = *reinterpret_cast<const f32x4*>(hid_s + j4);
-          e0 = fmaf(w[0], h[0], e0); e1 = fmaf(w[1], h[1], e1); e2 = fmaf(w[2], h[2], e2); e3 = fmaf(w[3], h[3], e3);
+      for (int r0 = 0; r0 < R; r0 += RB) {
+        float e[RB][2];
+#pragma unroll
+        for (int rr = 0; rr < RB; rr++) { e[rr][0] = 0.f; e[rr][1] = 0.f; }
+        for (int v0 = 0; v0 < V; v0 += VB) {
+          if (r0 | v0 | (img - img0)) issue(r0, v0);          // (the first batch is already in flight)
+#pragma unroll
+          for (int vv = 0; vv < VB; vv++) {
+            if (v0 + vv < V) {
+              const f32x4 h0 = *reinterpret_cast<const f32x4*>(hid_s + (v0 + vv) * JV);
+              f32x4 h1 = h0;
+              if constexpr (BF16) h1 = *reinterpret_cast<const f32x4*>(hid_s + (v0 + vv) * JV + 4);
+#pragma unroll
+              for (int rr = 0; rr < RB; rr++) {
+                const raw_t w = wv[rr][vv];
+                if constexpr (BF16) {
+                  e[rr][0] = fmaf(__uint_as_float(w[0] << 16), h0[0], e[rr][0]); e[rr][1] = fmaf(__uint_as_float(w[0] & 0xffff0000u), h0[1], e[rr][1]);
+                  e[rr][0] = fmaf(__uint_as_float(w[1] << 16), h0[2], e[rr][0]); e[rr][1] = fmaf(__uint_as_float(w[1] & 0xffff0000u), h0[3], e[rr][1]);
+                  e[rr][0] = fmaf(__uint_as_float(w[2] << 16), h1[0], e[rr][0]); e[rr][1] = fmaf(__uint_as_float(w[2] & 0xffff0000u), h1[1], e[rr][1]);
+                  e[rr][0] = fmaf(__uint_as_float(w[3] << 16), h1[2], e[rr][0]); e[rr][1] = fmaf(__uint_as_float(w[3] & 0xffff0000u), h1[3], e[rr][1]);
+                } else {
+                  e[rr][0] = fmaf(w[0], h0[0], e[rr][0]); e[rr][1] = fmaf(w[1], h0[1], e[rr][1]);
+                  e[rr][0] = fmaf(w[2], h0[2], e[rr][0]); e[rr][1] = fmaf(w[3], h0[3], e[rr][1]);
+                }
+              }
+            }
+          }
         }
-        sc[k] = sigmoidf((e0 + e1) + (e2 + e3));
+#pragma unroll
+        for (int rr = 0; rr < RB; rr++) {
+          const int k = ((r0 + rr) << 8) + threadIdx.x;
+          if (k < K) sc[k] = sigmoidf((e[rr][0] + e[rr][1]) + a.se_be[k]);
+        }
       }
       __syncthreads();
     }
@@ -239,13 +289,22 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
   }
 }
 
+// squeeze-excite prologue variant of a launch (also names the device function, hep_kernel_symbol)
+int pw_se_variant(const PwArgs& a) {
+  if (a.sq <= 0 || a.act == ACT_SWISH) return 0;          // (sq is set by the planner for project convs only)
+  return (a.K > 256 || a.sqp / (a.bf16 ? 8 : 4) > 2) ? 2 : 1;
+}
+
 template <bool BF16, int MT, int MODE>
 static void launch_nt(const PwArgs& a, dim3 grid, hipStream_t s) {
   // dynamic LDS of the squeeze-excite prologue: scale [se_nimg][K] | hidden [sqp] | helper-group row sums [<= 256]
-  const size_t lds = a.hpart ? ((size_t)a.se_nimg * a.K + a.sqp + 256 + a.sqp) * sizeof(float) : 0;
+  const size_t lds = a.sq > 0 ? ((size_t)a.se_nimg * a.K + a.sqp + 256 + a.sqp) * sizeof(float) : 0;
+  const int sev = pw_se_variant(a);
   switch (a.NT) {
-#define CASE(n) case n: if (a.act == ACT_SWISH) hipLaunchKernelGGL((pw_gemm_kernel<BF16, MT, n, MODE, ACT_SWISH>), grid, dim3(256), lds, s, a); \
-                else hipLaunchKernelGGL((pw_gemm_kernel<BF16, MT, n, MODE, ACT_NONE>), grid, dim3(256), lds, s, a); break;
+#define CASE(n) case n: if (a.act == ACT_SWISH) hipLaunchKernelGGL((pw_gemm_kernel<BF16, MT, n, MODE, ACT_SWISH, 0>), grid, dim3(256), 0, s, a); \
+                else if (sev == 0) hipLaunchKernelGGL((pw_gemm_kernel<BF16, MT, n, MODE, ACT_NONE, 0>), grid, dim3(256), 0, s, a); \
+                else if (sev == 1) hipLaunchKernelGGL((pw_gemm_kernel<BF16, MT, n, MODE, ACT_NONE, 1>), grid, dim3(256), lds, s, a); \
+                else hipLaunchKernelGGL((pw_gemm_kernel<BF16, MT, n, MODE, ACT_NONE, 2>), grid, dim3(256), lds, s, a); break;
     CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
 #undef CASE
   }
