@@ -14,7 +14,7 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64
 import torch  # noqa: F401  (must precede loading libhep.so, see module docstring)
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libhep.so")
-HEP_F32, HEP_BF16 = 0, 1
+HEP_F32, HEP_BF16, HEP_FP8 = 0, 1, 2
 FLAG_KEEP_INTERMEDIATES, FLAG_NO_GRAPH = 1, 2
 OUT_K = (4, 1, 3, 3, 63)
 
@@ -44,6 +44,7 @@ SYMBOLS = {
     "hep_kernel_count": (c_int, [_P, c_int]),
     "hep_kernel_info": (c_int, [_P, c_int, c_int, POINTER(c_char_p), POINTER(c_double), POINTER(c_double)]),
     "hep_kernel_symbol": (c_int, [_P, c_int, POINTER(c_char_p)]),
+    "hep_fp8_scale": (c_int, [_P, c_int, POINTER(c_float)]),
     "hep_profile": (c_int, [_P, c_int, c_int, POINTER(c_float), _FP]),
     "hep_profile_concurrent": (c_int, [_P, c_int, c_int, c_int, _FP]),
 }

@@ -5,6 +5,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <math.h>
+
 #include <chrono>
 #include <fstream>
 #include <memory>
@@ -115,6 +117,53 @@ int run_forward(Session* s, const float* in_dev, const int64_t* strides, int bat
 
 }  // namespace hep
 
+// fp8 sessions: one power-of-two scale per quantised GEMM input, from the amax of that tensor on a deterministic
+// calibration batch (pseudo-normal frames) run eagerly through the session's own kernels: the scale of a launch is set
+// before the launch runs, so every later tensor already sees the quantised arithmetic in front of it.  The e4m3
+// conversion saturates at +-448 * scale, and the scale carries 2x headroom over the calibration amax.
+static int calibrate_fp8(Session& s) {
+  HIPRET(hipSetDevice(s.device));
+  const int nb = std::min(s.lane_batch, 2);
+  const size_t in_floats = (size_t)3 * s.size * s.size;
+  if (!s.d_in) HIPRET(hipMalloc((void**)&s.d_in, in_floats * s.max_batch * 4));
+  {
+    std::vector<float> x(in_floats * nb);
+    uint64_t st = 0x9E3779B97F4A7C15ull;
+    auto u01 = [&]() { st = st * 6364136223846793005ull + 1442695040888963407ull; return ((st >> 11) + 0.5) * (1.0 / 9007199254740992.0); };
+    for (size_t i = 0; i + 1 < x.size(); i += 2) {          // Box-Muller
+      const double r = sqrt(-2.0 * log(u01())), t = 6.283185307179586 * u01();
+      x[i] = (float)(r * cos(t)); x[i + 1] = (float)(r * sin(t));
+    }
+    HIPRET(hipMemcpy(s.d_in, x.data(), x.size() * 4, hipMemcpyHostToDevice));
+  }
+  unsigned* d_m = nullptr;
+  HIPRET(hipMalloc((void**)&d_m, 4));
+  const int64_t S = s.size; const int64_t strides[4] = {3 * S * S, S * S, S, 1};
+  for (size_t i = 0; i < s.ops.size(); i++) {
+    Op& o = s.ops[i];
+    const bool q = (o.kind == OP_PW && o.pw.fp8) || (o.kind == OP_MBF && o.mbf.fp8);
+    if (q) {
+      const TensorDesc& t = s.tensors[o.reads[0]];
+      hipMemsetAsync(d_m, 0, 4, s.stream);
+      launch_amax_bf16(s.tptr(o.reads[0], 0), (int64_t)nb * t.H * t.W * t.C, d_m, s.stream);
+      unsigned bits = 0;
+      if (hipMemcpyAsync(&bits, d_m, 4, hipMemcpyDeviceToHost, s.stream) != hipSuccess || hipStreamSynchronize(s.stream) != hipSuccess) {
+        hipFree(d_m); return fail(HEP_ERR_DEVICE, "fp8 calibration failed");
+      }
+      float amax; memcpy(&amax, &bits, 4);
+      float sc = 1.f;
+      if (amax > 0.f && amax < 3e38f) sc = exp2f(ceilf(log2f(2.f * amax / 448.f)));
+      for (auto& lo : s.lane_ops) { if (o.kind == OP_PW) lo[i].pw.a_scale = sc; else lo[i].mbf.a_scale = sc; }
+      if (o.kind == OP_PW) o.pw.a_scale = sc; else o.mbf.a_scale = sc;
+    }
+    launch_op(s, s.lane_ops[0][i], nb, s.stream, s.d_in, strides);
+  }
+  hipError_t e = hipStreamSynchronize(s.stream);
+  hipFree(d_m);
+  if (e != hipSuccess || (e = hipGetLastError()) != hipSuccess) return fail(HEP_ERR_DEVICE, std::string("fp8 calibration: ") + hipGetErrorString(e));
+  return 0;
+}
+
 extern "C" {
 
 int hep_abi_version(void) { return HEP_ABI_VERSION; }
@@ -131,7 +180,7 @@ int hep_create_from_memory(const void* pack, size_t pack_bytes, int phi, int siz
   if (!out) return fail(HEP_ERR_INVALID, "out is NULL");
   *out = nullptr;
   if (!pack || pack_bytes < 12) return fail(HEP_ERR_PACK, "weight pack: empty");
-  if (dtype != HEP_F32 && dtype != HEP_BF16) return fail(HEP_ERR_INVALID, "dtype must be HEP_F32 or HEP_BF16");
+  if (dtype != HEP_F32 && dtype != HEP_BF16 && dtype != HEP_FP8) return fail(HEP_ERR_INVALID, "dtype must be HEP_F32, HEP_BF16 or HEP_FP8");
   if (max_batch < 1 || max_batch > 4096) return fail(HEP_ERR_INVALID, "max_batch out of range (1..4096)");
   if (size < 128 || size > 2048 || size % 128 != 0)
     return fail(HEP_ERR_UNSUPPORTED, "size must be a multiple of 128 in [128, 2048] (P7 has stride 128)");
@@ -158,6 +207,7 @@ int hep_create_from_memory(const void* pack, size_t pack_bytes, int phi, int siz
   }
   int rc = build_session(&s, pk, &err);
   if (rc != 0) return fail(rc, err);
+  if (dtype == HEP_FP8) if (int rc2 = calibrate_fp8(s)) return rc2;
   *out = h.release();
   return 0;
 }
@@ -461,15 +511,23 @@ int hep_kernel_info(const hep_handle* h, int batch, int i, const char** name, do
   return 0;
 }
 
+int hep_fp8_scale(const hep_handle* h, int i, float* a_scale) {
+  if (!h || !a_scale || i < 0 || i >= (int)h->s.ops.size()) return fail(HEP_ERR_INVALID, "bad kernel index");
+  const Op& o = h->s.ops[i];
+  *a_scale = (o.kind == OP_PW && o.pw.fp8) ? o.pw.a_scale : ((o.kind == OP_MBF && o.mbf.fp8) ? o.mbf.a_scale : 0.f);
+  return 0;
+}
+
 int hep_kernel_symbol(const hep_handle* h, int i, const char** symbol) {
   if (!h || !symbol || i < 0 || i >= (int)h->s.ops.size()) return fail(HEP_ERR_INVALID, "bad kernel index");
   static thread_local std::string buf;
   const Op& o = h->s.ops[i];
   const char* t = h->s.dtype ? "true" : "false";
+  const int prec = o.kind == OP_PW ? (o.pw.fp8 ? 2 : (h->s.dtype ? 1 : 0)) : 0;
   char tmp[128];
   switch (o.kind) {
     case OP_STEM: snprintf(tmp, sizeof tmp, "stem_kernel<%s>", t); break;
-    case OP_PW: snprintf(tmp, sizeof tmp, "pw_gemm_kernel<%s, %d, %d, %d, %d, %d>", t, o.pw.MT, o.pw.NT, o.pw.mode, o.pw.act == ACT_SWISH ? 1 : 0, pw_se_variant(o.pw)); break;
+    case OP_PW: snprintf(tmp, sizeof tmp, "pw_gemm_kernel<%d, %d, %d, %d, %d, %d>", prec, o.pw.MT, o.pw.NT, o.pw.mode, o.pw.act == ACT_SWISH ? 1 : 0, pw_se_variant(o.pw)); break;
     case OP_DW: snprintf(tmp, sizeof tmp, "dw_kernel<%s, %d, %d, %d>", t, o.dw.k, o.dw.s, o.dw.TW); break;
     case OP_POOL: snprintf(tmp, sizeof tmp, "pool_kernel<%s>", t); break;
     case OP_PWG: snprintf(tmp, sizeof tmp, "pw_group_kernel<%s>", t); break;

@@ -35,6 +35,22 @@ template <bool FAST> __device__ __forceinline__ float apply_act_t(float x, int a
   return act == 1 ? swish_t<FAST>(x) : (act == 2 ? sigmoid_t<FAST>(x) : x);
 }
 
+// 8 bf16 activations (optionally times 8 squeeze-excite scales) -> 8 e4m3 bytes: x * inv_scale, saturated to +-448, RNE
+__device__ __forceinline__ long cvt_fp8x8(u32x4 raw, const float* s8, float inv_scale) {
+  float f[8];
+#pragma unroll
+  for (int q = 0; q < 4; q++) { f[2 * q] = __uint_as_float(raw[q] << 16); f[2 * q + 1] = __uint_as_float(raw[q] & 0xffff0000u); }
+  if (s8) {
+#pragma unroll
+    for (int q = 0; q < 8; q++) f[q] *= s8[q];
+  }
+#pragma unroll
+  for (int q = 0; q < 8; q++) f[q] = fminf(fmaxf(f[q] * inv_scale, -448.f), 448.f);
+  int lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], 0, false); lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
+  int hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], 0, false); hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
+  return (long)(((unsigned long)(unsigned)hi << 32) | (unsigned)lo);
+}
+
 // 8 consecutive channels <-> 8 floats
 template <bool BF16> struct Vec8;
 template <> struct Vec8<true> {

@@ -87,7 +87,7 @@ struct Session {
   void* tptr(int id, int lane = 0) const { const TensorDesc& t = tensors[id]; return t.external ? t.ext_ptr : (void*)(d_arena + (size_t)lane * arena_bytes + t.offset); }
   int lanes_for(int batch) const { return (batch + lane_batch - 1) / lane_batch; }
   int lane_count(int batch, int lane) const { return std::min(lane_batch, batch - lane * lane_batch); }
-  size_t esize() const { return dtype == 1 ? 2 : 4; }
+  size_t esize() const { return dtype ? 2 : 4; }      // bf16 storage in bf16 AND fp8 sessions
 };
 
 int build_session(Session* s, const Pack& pack, std::string* err);

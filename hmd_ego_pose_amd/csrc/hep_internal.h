@@ -35,6 +35,7 @@ struct PwArgs {
   int M, K, N, tilesN; // tilesN = ceil(N/16); W holds tilesN*16 rows
   int HW;              // rows per image (for se)
   int act, bf16, MT, NT;
+  int fp8; const float* wscale; float a_scale;   // fp8 operands (k_pw_impl.h): W is e4m3 [tilesN*16][K], per-row scales, per-tensor activation scale
   int mode;            // wave arrangement inside a workgroup: 0 along M, 1 along N, 2 split-K (k_pw.hip)
 };
 
@@ -68,6 +69,7 @@ struct MbfArgs {
   int CC;              // expanded channels per workgroup (8 * power of two)
   int ts;              // output tile side: 8, or 16 (stride-1 layers on maps >= 16x16; k_mbf.hip)
   size_t off_e, off_we, off_w, lds_bytes;
+  int fp8; const float* we_scale; float a_scale;   // fp8 sessions: e4m3 expand weights (rows padded to 16 bytes), per-channel / per-tensor scales
   int trace;           // profiling builds (-DHEP_MBF_TRACE): this launch writes its phase time stamps
 };
 
@@ -145,6 +147,7 @@ void launch_decode(const DecodeArgs&, hipStream_t);
 void launch_export(const ExportArgs&, hipStream_t);
 void launch_preprocess(const PreprocArgs&, hipStream_t);
 void launch_filter(const FilterArgs&, hipStream_t);
+void launch_amax_bf16(const void* x, int64_t n, unsigned* out /* float bits, zeroed */, hipStream_t);
 int dw_blocks_per_image(int Ho, int Wo, int C, int TW);
 void sep_lds_layout(int C, int bf16, int ts, int max_cols_f32, int max_cols_map, SepArgs* a);
 int sep_prepare(void);   // raises the dynamic-LDS limit of the sepconv kernels (call once per device)

@@ -2,6 +2,7 @@
 // folding + weight layout, and the launch plan (one Op per kernel launch) with a
 // liveness-based activation arena.
 #include <math.h>
+#include <cmath>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -154,6 +155,23 @@ static uint16_t f32_to_bf16(float f) {
   return (uint16_t)(u >> 16);
 }
 
+// fp32 -> OCP e4m3fn (bias 7, no infinities, max 448), round to nearest even, saturating
+static uint8_t f32_to_e4m3(float f) {
+  const uint8_t sign = std::signbit(f) ? 0x80 : 0;
+  float a = fabsf(f);
+  if (a != a) return sign | 0x7f;
+  if (a >= 464.f) return sign | 0x7e;                                  // beyond the last rounding boundary: +-448
+  if (a < 0.015625f) {                                                 // below 2^-6: subnormals, step 2^-9
+    const int q = (int)nearbyintf(a * 512.f);
+    return sign | (uint8_t)q;                                          // q == 8 is the smallest normal, 0x08
+  }
+  int e; const float m = frexpf(a, &e);                                // a = m * 2^e, m in [0.5, 1)
+  int ee = e - 1, mant = (int)nearbyintf((m * 2.f - 1.f) * 8.f);
+  if (mant == 8) { mant = 0; ee++; }
+  if (ee > 8 || (ee == 8 && mant > 6)) return sign | 0x7e;
+  return sign | (uint8_t)(((ee + 7) << 3) | mant);
+}
+
 struct WBuilder {
   std::vector<unsigned char> host;
   int dtype;
@@ -167,7 +185,20 @@ struct WBuilder {
     memcpy(host.data() + off, v.data(), v.size() * 4);
     return off;
   }
-  size_t put_typed(const std::vector<float>& v) {   // dtype elements
+  // e4m3 rows [rows][stride] of a [rows][K] matrix, one scale per row (amax / 448): w ~ e4m3 * scale
+  size_t put_fp8(const std::vector<float>& v, int rows, int K, int stride, std::vector<float>* scales) {
+    const size_t off = alloc((size_t)rows * stride);
+    scales->assign(rows, 1.f);
+    for (int n = 0; n < rows; n++) {
+      float amax = 0.f;
+      for (int k = 0; k < K; k++) amax = std::max(amax, fabsf(v[(size_t)n * K + k]));
+      const float sc = amax > 0.f ? amax / 448.f : 1.f;
+      (*scales)[n] = sc;
+      for (int k = 0; k < K; k++) host[off + (size_t)n * stride + k] = f32_to_e4m3(v[(size_t)n * K + k] / sc);
+    }
+    return off;
+  }
+  size_t put_typed(const std::vector<float>& v) {   // dtype elements (fp8 sessions store bf16 everywhere except the quantised weights)
     if (dtype == 0) return put_f32(v);
     size_t off = alloc(v.size() * 2);
     uint16_t* d = (uint16_t*)(host.data() + off);
@@ -196,7 +227,7 @@ static bool fold_bn(const Pack& pk, const std::string& p, int c, BnFold* out, st
 // index after the plan is complete: each Op records symbolic references here.
 struct Ref { int op; int field; int seg; int idx; size_t woff; int tensor; };
 enum { F_STEM_W, F_STEM_B, F_STEM_OUT, F_PW_A, F_PW_W, F_PW_B, F_PW_RES, F_PW_OUT, F_DW_IN, F_DW_W, F_DW_B,
-       F_DW_OUT, F_DW_PART, F_DW_WR, F_MBF_IN, F_MBF_WE, F_MBF_BE, F_MBF_WDW, F_MBF_BDW, F_MBF_OUT, F_MBF_PART, F_MBF_WR, F_PW_HPART, F_PW_SEBR, F_PW_SEWE, F_PW_SEBE, F_POOL_IN, F_POOL_OUT, F_PWG_A, F_PWG_W, F_PWG_B, F_PWG_OUT,
+       F_DW_OUT, F_DW_PART, F_DW_WR, F_MBF_IN, F_MBF_WE, F_MBF_BE, F_MBF_WDW, F_MBF_BDW, F_MBF_OUT, F_MBF_PART, F_MBF_WR, F_MBF_WESCALE, F_PW_WSCALE, F_PW_HPART, F_PW_SEBR, F_PW_SEWE, F_PW_SEBE, F_POOL_IN, F_POOL_OUT, F_PWG_A, F_PWG_W, F_PWG_B, F_PWG_OUT,
        F_SEG_SRC, F_SEG_WDW, F_SEG_WPW, F_SEG_BIAS, F_SEG_OUT };
 
 struct Planner {
@@ -235,7 +266,7 @@ struct Planner {
   // squeeze-excite of a project conv: the front kernel's partial reduce-FC rows + the rest of the two FCs
   struct SeSpec { int hpart_t = -1, rows = 0, sq = 0, sqp = 0; float inv_hw = 0.f; size_t br = 0, we = 0, be = 0; };
   int add_pw(const std::string& name, int in_t, int HW, int K, int N, const std::string& wkey, const std::string& bkey,
-             const std::string& bnkey, int act, const SeSpec* se, int res_t, const std::string& out_name, int H, int W) {
+             const std::string& bnkey, int act, const SeSpec* se, int res_t, const std::string& out_name, int H, int W, bool quant = false) {
     const PackTensor* w = get(wkey, {N, K, 1, 1});
     const PackTensor* cb = bkey.empty() ? nullptr : get(bkey, {N});
     BnFold bn;
@@ -276,11 +307,16 @@ struct Planner {
         if (o.pw.mode != 0 && strips >= 8 && !(e && atoi(e) == 0)) { o.pw.MT = 2; o.pw.NT = std::min(o.pw.NT, 4); }
       }
     }
-    wref(op, F_PW_W, wb.put_typed(wf)); wref(op, F_PW_B, wb.put_f32(bf));
-    tref(op, F_PW_A, in_t, false); tref(op, F_PW_OUT, out_t, true);
+    tref(op, F_PW_A, in_t, false); tref(op, F_PW_OUT, out_t, true);     // (reads[0] is the GEMM's activation operand: fp8 calibration)
+    if (quant && s->dtype == 2) {     // fp8 session: e4m3 weights, one scale per output channel behind the BN fold
+      std::vector<float> sc;
+      wref(op, F_PW_W, wb.put_fp8(wf, tilesN * 16, K, K, &sc)); wref(op, F_PW_WSCALE, wb.put_f32(sc));
+      o.pw.fp8 = 1; o.pw.a_scale = 1.f;
+    } else wref(op, F_PW_W, wb.put_typed(wf));
+    wref(op, F_PW_B, wb.put_f32(bf));
     if (res_t >= 0) tref(op, F_PW_RES, res_t, false);
     o.act_bytes_per_image = ((double)HW * K + (double)HW * N * (res_t >= 0 ? 2 : 1)) * es();
-    o.weight_bytes = (double)N * K * es();
+    o.weight_bytes = (double)N * K * (o.pw.fp8 ? 1.0 : es());
     o.flops_per_image = 2.0 * HW * K * N;
     if (se) {
       tref(op, F_PW_HPART, se->hpart_t, false);
@@ -411,18 +447,23 @@ struct Planner {
         const int rows = (b.cexp + 15) / 16 * 16;
         std::vector<float> wf((size_t)rows * b.cin, 0.f);
         for (int n = 0; n < b.cexp; n++) for (int k = 0; k < b.cin; k++) wf[(size_t)n * b.cin + k] = w->data[(size_t)n * b.cin + k] * bn0.scale[n];
-        wref(op, F_MBF_WE, wb.put_typed(wf)); wref(op, F_MBF_BE, wb.put_f32(bn0.shift));
+        if (s->dtype == 2) {
+          std::vector<float> sc;
+          wref(op, F_MBF_WE, wb.put_fp8(wf, rows, b.cin, (b.cin + 15) & ~15, &sc)); wref(op, F_MBF_WESCALE, wb.put_f32(sc));
+          m.fp8 = 1; m.a_scale = 1.f;
+        } else wref(op, F_MBF_WE, wb.put_typed(wf));
+        wref(op, F_MBF_BE, wb.put_f32(bn0.shift));
       }
       wref(op, F_MBF_WDW, wb.put_f32(wdw)); wref(op, F_MBF_BDW, wb.put_f32(bn1.shift));
       tref(op, F_MBF_IN, x, false); tref(op, F_MBF_OUT, dw_t, true); tref(op, F_MBF_PART, part_t, true);
       o.act_bytes_per_image = ((double)Hin * Win * b.cin + (double)Ho * Wo * b.cexp) * es();
-      o.weight_bytes = (b.expand ? (double)b.cexp * b.cin * es() : 0.0) + (double)b.k * b.k * b.cexp * 4;
+      o.weight_bytes = (b.expand ? (double)b.cexp * b.cin * (m.fp8 ? 1.0 : es()) : 0.0) + (double)b.k * b.k * b.cexp * 4;
       o.flops_per_image = (b.expand ? 2.0 * Hin * Win * b.cin * b.cexp : 0.0) + 2.0 * b.k * b.k * Ho * Wo * b.cexp;
     } else {
       if (b.expand) {
         snprintf(nm, sizeof nm, "b%d.expand", i);
         x = add_pw(nm, x, Hin * Win, b.cin, b.cexp, p + "._expand_conv.conv.weight", "", p + "._bn0", ACT_SWISH, nullptr, -1,
-                   std::string(nm), Hin, Win);
+                   std::string(nm), Hin, Win, true);
         if (!ok) return -1;
       }
       // depthwise on its own: from global memory for the big maps (bandwidth-bound, k_dw.hip), through
@@ -475,7 +516,7 @@ struct Planner {
     // project + bn2 (+ residual), SE scale applied on the GEMM's input side
     snprintf(nm, sizeof nm, "b%d.project", i);
     x = add_pw(nm, dw_t, Ho * Wo, b.cexp, b.cout, p + "._project_conv.conv.weight", "", p + "._bn2", ACT_NONE, &se,
-               b.skip ? inp : -1, std::string("block") + std::to_string(i), Ho, Wo);
+               b.skip ? inp : -1, std::string("block") + std::to_string(i), Ho, Wo, true);
     *H = Ho; *W = Wo;
     return x;
   }
@@ -872,6 +913,8 @@ int build_session(Session* s, const Pack& pack, std::string* err) {
         case F_MBF_OUT: o.mbf.out = ptr; break;
         case F_MBF_PART: o.mbf.hpart = (float*)ptr; break;
         case F_MBF_WR: o.mbf.se_wr = (const float*)ptr; break;
+        case F_MBF_WESCALE: o.mbf.we_scale = (const float*)ptr; break;
+        case F_PW_WSCALE: o.pw.wscale = (const float*)ptr; break;
         case F_POOL_IN: o.pool.in = ptr; break;
         case F_POOL_OUT: o.pool.out = ptr; break;
         case F_PWG_A: o.pwg.seg[r.seg].A = ptr; break;

@@ -79,6 +79,9 @@ __global__ __launch_bounds__(TS == 16 ? 1024 : 512) void mbf_kernel(MbfArgs a) {
   float* wdw_s = reinterpret_cast<float*>(smem + a.off_w);         // [KS*KS][CC]
   float* be_s = wdw_s + KS * KS * a.CC;                            // [CC] expand bias
   float* bdw_s = be_s + a.CC;                                      // [CC] depthwise bias
+  const bool F8 = BF16 && a.fp8;                                   // e4m3 operands in the expand MFMA (uniform)
+  const int K16 = (K + 15) & ~15, KP8 = K16 + 16;                  // fp8 weight rows: bytes in memory / in LDS
+  unsigned char* w8_s = smem + a.off_we;
 
   // ---- phase A: everything this workgroup needs, global -> LDS, all loads issued in batches of 8
   //      before the first LDS store (one memory round trip per batch): depthwise weights + biases,
@@ -134,6 +137,9 @@ __global__ __launch_bounds__(TS == 16 ? 1024 : 512) void mbf_kernel(MbfArgs a) {
     // the zero padding of the depthwise conv and is written as zeros right here
     const int n_wrows = a.has_expand ? ntiles * 16 : 0, n_rows = n_wrows + (a.has_expand ? n_in : PIN);
     const T* Wg = reinterpret_cast<const T*>(a.we) + (int64_t)c0 * K;
+    // fp8 sessions: the expand weights are e4m3, rows padded to K16 = ceil16(K) bytes in memory and K16 + 16 in LDS
+    const unsigned char* Wg8 = reinterpret_cast<const unsigned char*>(a.we) + (int64_t)c0 * K16;
+    const int vecs_w = F8 ? K16 >> 4 : vecs;
     if (a.has_expand) {
       const int nv = PIN * EP * (int)sizeof(T) / 16;               // the whole [PIN][EP] tile in 16-byte vectors
       for (int i = threadIdx.x; i < nv; i += MBF_THREADS) reinterpret_cast<u32x4*>(e_s)[i] = (u32x4){0, 0, 0, 0};
@@ -144,9 +150,9 @@ __global__ __launch_bounds__(TS == 16 ? 1024 : 512) void mbf_kernel(MbfArgs a) {
       for (int j = 0; j < NB; j++) {
         const int row = base + j * rstride + row0;
         x0[j] = raw_t{}; x1[j] = raw_t{};
-        if (v < vecs && row < n_rows) {
+        if (v < (row < n_wrows ? vecs_w : vecs) && row < n_rows) {
           const T* src = nullptr;
-          if (row < n_wrows) src = Wg + (int64_t)row * K + v * 8;
+          if (row < n_wrows) src = F8 ? reinterpret_cast<const T*>(Wg8 + (int64_t)row * K16 + v * 16) : Wg + (int64_t)row * K + v * 8;
           else {
             int p = row - n_wrows;
             if (a.has_expand) { const int ri = fast_div_u(p, wi_rcp); p = (r0 + ri) * PW + q0 + (p - ri * wi); }
@@ -160,8 +166,8 @@ __global__ __launch_bounds__(TS == 16 ? 1024 : 512) void mbf_kernel(MbfArgs a) {
 #pragma unroll
       for (int j = 0; j < NB; j++) {
         const int row = base + j * rstride + row0;
-        if (v < vecs && row < n_rows) {
-          raw_t* d = row < n_wrows ? reinterpret_cast<raw_t*>(w_s + (int64_t)row * KP + v * 8)
+        if (v < (row < n_wrows ? vecs_w : vecs) && row < n_rows) {
+          raw_t* d = row < n_wrows ? (F8 ? reinterpret_cast<raw_t*>(w8_s + (int64_t)row * KP8 + v * 16) : reinterpret_cast<raw_t*>(w_s + (int64_t)row * KP + v * 8))
                                    : reinterpret_cast<raw_t*>(dst + (int64_t)(row - n_wrows) * pitch + v * 8);
           d[0] = x0[j]; if (!BF16) d[1] = x1[j];
         }
@@ -186,16 +192,26 @@ __global__ __launch_bounds__(TS == 16 ? 1024 : 512) void mbf_kernel(MbfArgs a) {
       const T* arow0 = a_s + (int64_t)m0 * KP + KLANE * g;
       const T* arow1 = a_s + (int64_t)m1 * KP + KLANE * g;
       f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+      const unsigned char* w8row = w8_s + (int64_t)(nt * 16 + r) * KP8 + 8 * g;
+      const float inv_as = F8 ? 1.0f / a.a_scale : 1.0f;
 #pragma unroll 3
       for (int ks = 0; ks < ksteps; ks++) {
         const int k = ks * KSTEP + KLANE * g;
         raw_t wf = {}, xa0 = {}, xa1 = {};
+        u32x2 wf8 = {};
         if (k < K) {
-          wf = *reinterpret_cast<const raw_t*>(wrow + ks * KSTEP);
+          if (F8) wf8 = *reinterpret_cast<const u32x2*>(w8row + ks * 32);
+          else wf = *reinterpret_cast<const raw_t*>(wrow + ks * KSTEP);
           if (m0 < n_in) xa0 = *reinterpret_cast<const raw_t*>(arow0 + ks * KSTEP);
           if (m1 < n_in) xa1 = *reinterpret_cast<const raw_t*>(arow1 + ks * KSTEP);
         }
         if constexpr (BF16) {
+          if (F8) {
+            const long wl = __builtin_bit_cast(long, wf8);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(wl, cvt_fp8x8(xa0, nullptr, inv_as), acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(wl, cvt_fp8x8(xa1, nullptr, inv_as), acc1, 0, 0, 0);
+            continue;
+          }
           acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf), __builtin_bit_cast(bf16x8, xa0), acc0, 0, 0, 0);
           acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf), __builtin_bit_cast(bf16x8, xa1), acc1, 0, 0, 0);
         } else {
@@ -206,6 +222,8 @@ __global__ __launch_bounds__(TS == 16 ? 1024 : 512) void mbf_kernel(MbfArgs a) {
       const int n = nt * 16 + 4 * g;          // lane: 4 consecutive expanded channels of tile pixels m0, m1
       if (n < cc) {
         const f32x4 bias = *reinterpret_cast<const f32x4*>(be_s + n);
+        f32x4 ws = (f32x4){1.f, 1.f, 1.f, 1.f};
+        if (F8) ws = *reinterpret_cast<const f32x4*>(a.we_scale + c0 + n) * a.a_scale;       // dequantisation: a_scale * w_scale[n]
 #pragma unroll
         for (int half = 0; half < 2; half++) {
           const int m = half ? m1 : m0;
@@ -214,7 +232,7 @@ __global__ __launch_bounds__(TS == 16 ? 1024 : 512) void mbf_kernel(MbfArgs a) {
             const int ri = fast_div_u(m, wi_rcp), p = (r0 + ri) * PW + q0 + (m - ri * wi);   // tile position of inside pixel m
             float v[4];
 #pragma unroll
-            for (int q = 0; q < 4; q++) v[q] = swish_t<BF16>(acc[q] + bias[q]);
+            for (int q = 0; q < 4; q++) v[q] = swish_t<BF16>(fmaf(acc[q], ws[q], bias[q]));
             V::store4(e_s, (int64_t)p * EP + n, v);
           }
         }

@@ -1,5 +1,7 @@
 // k_post.hip - decode half of the path on gfx950: box / translation decode and the
 // detection filter (score threshold -> greedy NMS -> first max_det survivors -> -1 padding).
+#include <algorithm>
+
 #include "hep_dev.h"
 #include "hep_internal.h"
 
@@ -192,4 +194,21 @@ __global__ __launch_bounds__(256) void preprocess_kernel(PreprocArgs a) {
 void launch_preprocess(const PreprocArgs& a, hipStream_t s) {
   const int64_t total = (int64_t)a.B * a.S * a.S * 3;
   hipLaunchKernelGGL(preprocess_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// amax of a bf16 tensor (fp8 calibration at hep_create: one power-of-two scale per quantised GEMM input).
+// Non-negative floats order like their bit patterns, so the block maxima meet in one integer atomicMax
+// (a maximum is order-independent: the result is deterministic).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void amax_kernel(const uint16_t* x, int64_t n, unsigned* out) {
+  float m = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = fmaxf(m, fabsf(bf16_bits_to_f32(x[i])));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0 && m == m) atomicMax(out, __float_as_uint(m));
+}
+void launch_amax_bf16(const void* x, int64_t n, unsigned* out, hipStream_t s) {
+  const int blocks = (int)std::min<int64_t>(1024, (n + 255) / 256);
+  hipLaunchKernelGGL(amax_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const uint16_t*>(x), n, out);
 }

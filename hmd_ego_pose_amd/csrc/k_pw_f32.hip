@@ -1,0 +1,3 @@
+// k_pw_f32.hip - the pointwise GEMM kernels of k_pw_impl.h for precision 0 (0 fp32, 1 bf16, 2 fp8 operands).
+#include "k_pw_impl.h"
+template void launch_pw_prec<0>(const PwArgs&, hipStream_t);

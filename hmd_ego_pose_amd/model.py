@@ -25,7 +25,7 @@ from . import _capi
 from .arch import OUT_WIDTH, get_arch, level_sizes, num_anchors_total, param_spec
 from .weights import pack_bytes
 
-_PRECISIONS = {"fp32": _capi.HEP_F32, "f32": _capi.HEP_F32, "bf16": _capi.HEP_BF16}
+_PRECISIONS = {"fp32": _capi.HEP_F32, "f32": _capi.HEP_F32, "bf16": _capi.HEP_BF16, "fp8": _capi.HEP_FP8}
 
 
 # --------------------------------------------------------------------------------------
@@ -150,6 +150,17 @@ class Session:
             sym = ctypes.c_char_p()
             _capi.check(l.hep_kernel_symbol(self.handle, i, ctypes.byref(sym)))
             out.append((nm.value.decode(), b.value, f.value, sym.value.decode()))
+        return out
+
+    def fp8_scales(self) -> Dict[str, float]:
+        """launch name -> calibrated per-tensor activation scale of its e4m3 GEMM (fp8 sessions; empty otherwise)."""
+        l = _capi.lib()
+        out = {}
+        for i, (name, *_rest) in enumerate(self.kernels(1)):
+            sc = ctypes.c_float()
+            _capi.check(l.hep_fp8_scale(self.handle, i, ctypes.byref(sc)))
+            if sc.value > 0:
+                out[name] = sc.value
         return out
 
     def profile(self, batch: int, iters: int = 20, per_kernel: bool = False):

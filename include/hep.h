@@ -52,7 +52,11 @@ typedef enum hep_status {
 
 typedef enum hep_dtype {
   HEP_F32 = 0,   /* fp32 storage, exact-fp32 MFMA (v_mfma_f32_16x16x4_f32): the parity mode        */
-  HEP_BF16 = 1   /* bf16 activations+weights, fp32 accumulate (v_mfma_f32_16x16x32_bf16): the bench */
+  HEP_BF16 = 1,  /* bf16 activations+weights, fp32 accumulate (v_mfma_f32_16x16x32_bf16): the bench */
+  HEP_FP8 = 2    /* bf16 session whose backbone pointwise convs (expand / project, 62 % of the MACs) run with OCP e4m3
+                    operands (v_mfma_f32_16x16x32_fp8_fp8, fp32 accumulate): weights stored as e4m3 with one scale per
+                    output channel behind the BN fold, activations converted on the fly with one power-of-two scale per
+                    tensor calibrated at hep_create; depthwise, BiFPN and heads stay bf16 (BASELINE config 5)        */
 } hep_dtype;
 
 /* hep_create flags */
@@ -149,6 +153,8 @@ int hep_debug_tensor(hep_handle* h, const char* name, int batch, float* out, siz
 int hep_kernel_count(const hep_handle* h, int batch);      /* launches in one forward                      */
 /* Per-launch description of the forward plan: name, algorithmic bytes and flops for `batch`. */
 int hep_kernel_info(const hep_handle* h, int batch, int i, const char** name, double* bytes, double* flops);
+/* fp8 sessions: the calibrated per-tensor activation scale of launch i (0 when the launch has no e4m3 operands). */
+int hep_fp8_scale(const hep_handle* h, int i, float* a_scale);
 /* Device function (as rocprofv3 --kernel-trace names it, e.g. "sep_kernel<true>") behind launch i. */
 int hep_kernel_symbol(const hep_handle* h, int i, const char** symbol);
 /* Time `iters` replays of the forward at `batch` with HIP events on the handle's own stream; when

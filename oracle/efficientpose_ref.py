@@ -237,8 +237,10 @@ def forward(sd: Mapping[str, torch.Tensor], x: torch.Tensor, phi: int, trace: Di
 #   q_w    pointwise (1x1) weights AFTER the BN scale is folded in, and the squeeze-excite
 #          expand FC weight (read by every project workgroup).  Depthwise, stem, SE reduce
 #          weights, biases and fusion weights stay fp32.
-#   q_pw   (fp8 variant) per-tensor-scaled operand quantiser of the backbone pointwise
-#          convs: called as q_pw(x, kind) with kind in {"act", "weight"}.
+#   q_pw   (fp8 sessions) replaces the backbone pointwise convs (expand / project): called as
+#          q_pw(x, w_folded, bias, tag) with tag "b{i}.expand" / "b{i}.project"; see
+#          ``make_q_pw_fp8`` (e4m3 operands, per-output-channel weight scale, per-tensor
+#          power-of-two activation scale taken from the device's calibration).
 # ======================================================================================
 def q_bf16(t: torch.Tensor) -> torch.Tensor:
     """Round to nearest-even bf16 and back (what v_cvt_pk_bf16_f32 does)."""
@@ -258,27 +260,54 @@ class _Emu:
         self.qw = q_w or ident
         self.q_pw = q_pw
 
-    def pw(self, x, w, bias, backbone=False):
-        """1x1 conv with an already folded weight [N,K,1,1]."""
-        if backbone and self.q_pw is not None:
-            return self.q_pw(x, w, bias)
+    def pw(self, x, w, bias, tag=None):
+        """1x1 conv with an already folded weight [N,K,1,1]; tag names a backbone conv (quantised in fp8 sessions)."""
+        if tag is not None and self.q_pw is not None:
+            return self.q_pw(x, w, bias, tag)
         return F.conv2d(x, self.qw(w), bias)
+
+
+E4M3_MAX = 448.0
+
+
+def q_e4m3(t: torch.Tensor) -> torch.Tensor:
+    """Round to OCP e4m3fn (nearest even, saturating at +-448 like the device conversion) and back."""
+    return torch.clamp(t, -E4M3_MAX, E4M3_MAX).to(torch.float8_e4m3fn).to(torch.float32)
+
+
+def make_q_pw_fp8(act_scales: Mapping[str, float]):
+    """The e4m3 pointwise conv of an fp8 device session (hmd_ego_pose_amd/csrc/k_pw_impl.h, k_mbf.hip): weights
+    w / sw[n] with sw[n] = max_k |w[n, k]| / 448 per output channel, activations x / sa with the power-of-two
+    per-tensor scale ``act_scales[tag]`` the device calibrated (Session.fp8_scales(): a fused front launch
+    "b{i}.front" carries the scale of its expand conv), exact products, fp32 accumulation, then * sa * sw[n] + bias."""
+    def q_pw(x, w, bias, tag):
+        sa = float(act_scales.get(tag, act_scales.get(tag.replace(".expand", ".front"), 0.0)))
+        if sa <= 0:
+            raise KeyError(f"no fp8 activation scale for {tag}")
+        amax = w.abs().amax(dim=(1, 2, 3), keepdim=True)
+        sw = torch.where(amax > 0, amax / E4M3_MAX, torch.ones_like(amax))
+        y = F.conv2d(q_e4m3(x / sa), q_e4m3(w / sw)) * (sa * sw.view(1, -1, 1, 1))
+        return y + bias.view(1, -1, 1, 1)
+    return q_pw
 
 
 def _mbconv_emu(E: _Emu, sd, p: str, blk: dict, x):
     inp = x
+    tag = "b" + p.rsplit(".", 1)[-1]
     if blk["e"] != 1:
         s0, b0 = _fold(sd, p + "._bn0")
-        x = E.qa(swish(E.pw(x, sd[p + "._expand_conv.conv.weight"] * s0[:, None, None, None], b0, backbone=True)))
+        x = E.qa(swish(E.pw(x, sd[p + "._expand_conv.conv.weight"] * s0[:, None, None, None], b0, tag + ".expand")))
     s1, b1 = _fold(sd, p + "._bn1")
     wdw = sd[p + "._depthwise_conv.conv.weight"] * s1[:, None, None, None]
     v = swish(conv_same(x, wdw, b1, stride=blk["s"], groups=wdw.shape[0]))
     sq = F.adaptive_avg_pool2d(v, 1)                                   # fp32 mean of the un-rounded values
     sq = swish(F.conv2d(sq, sd[p + "._se_reduce.conv.weight"], sd[p + "._se_reduce.conv.bias"]))
     sq = torch.sigmoid(F.conv2d(sq, E.qw(sd[p + "._se_expand.conv.weight"]), sd[p + "._se_expand.conv.bias"]))
-    a = E.qa(E.qa(v) * sq)                                             # stored depthwise output x scale -> GEMM operand
+    a = E.qa(v) * sq                                                   # stored depthwise output x scale -> GEMM operand
+    if E.q_pw is None:
+        a = E.qa(a)                                                    # (fp8 sessions convert the fp32 product straight to e4m3)
     s2, b2 = _fold(sd, p + "._bn2")
-    y = E.pw(a, sd[p + "._project_conv.conv.weight"] * s2[:, None, None, None], b2, backbone=True)
+    y = E.pw(a, sd[p + "._project_conv.conv.weight"] * s2[:, None, None, None], b2, tag + ".project")
     if blk["skip"]:
         y = y + inp
     return E.qa(y)
