@@ -316,10 +316,18 @@ int hep_anchors(int size, float* anchors, float* translation_anchors) {
 int hep_preprocess_u8_device(hep_handle* h, const uint8_t* rgb_hwc, int batch, int height, int width, float* out_hwc, void* stream) {
   if (!h || !rgb_hwc || !out_hwc || batch < 1 || height < 1 || width < 1) return fail(HEP_ERR_INVALID, "bad argument");
   Session& s = h->s;
-  if (std::max(height, width) != s.size)
-    return fail(HEP_ERR_UNSUPPORTED, "preprocess: max(height, width) must equal the network size (cv2.resize bilinear is parity-unpinned and not implemented)");
   HIPRET(hipSetDevice(s.device));
   PreprocArgs a; a.in = rgb_hwc; a.out = out_hwc; a.B = batch; a.H = height; a.W = width; a.S = s.size;
+  // colibri_common.py:631-642: scale = image_size / longer side; that side becomes image_size, the other int(side * scale);
+  // cv2.resize(image, (resized_width, resized_height)): with an explicit size the per-axis inverse scale is src / dst
+  const int side = std::max(height, width);
+  a.resize = side != s.size;
+  const double scale = (double)s.size / side;
+  a.nh = height > width ? s.size : (int)(height * scale);
+  a.nw = height > width ? (int)(width * scale) : s.size;
+  if (!a.resize) { a.nh = height; a.nw = width; }
+  a.inv_scale_x = (double)width / std::max(a.nw, 1); a.inv_scale_y = (double)height / std::max(a.nh, 1);
+  if (a.nh > s.size || a.nw > s.size || a.nh < 1 || a.nw < 1) return fail(HEP_ERR_UNSUPPORTED, "preprocess: resized frame does not fit the network size");
   launch_preprocess(a, (hipStream_t)stream);
   HIPRET(hipGetLastError());
   return 0;
@@ -462,6 +470,44 @@ int hep_filter(hep_handle* h, const float* boxes, const float* classification, c
   if (det_index) HIPRET(hipMemcpyAsync(det_index, ix_, M * 4, hipMemcpyDeviceToHost, s.stream));
   HIPRET(hipMemcpyAsync(det_count, ct_, (size_t)batch * 4, hipMemcpyDeviceToHost, s.stream));
   HIPRET(hipStreamSynchronize(s.stream));
+  return 0;
+}
+
+// ---- pose errors (evaluator) ----
+int hep_pose_errors_device(const float* points, int num_points, const float* rvec_gt, const float* t_gt, const float* rvec_pred,
+                           const float* t_pred, int num_pairs, int max_points, double* add, double* add_s, void* stream) {
+  if (!points || !rvec_gt || !t_gt || !rvec_pred || !t_pred || !add || !add_s) return fail(HEP_ERR_INVALID, "bad argument");
+  if (num_points < 1 || num_pairs < 0) return fail(HEP_ERR_INVALID, "num_points must be >= 1 and num_pairs >= 0");
+  if (max_points < 1 || max_points > 1024) return fail(HEP_ERR_UNSUPPORTED, "max_points must be in 1..1024 (the reference uses 1000)");
+  if (num_pairs == 0) return 0;
+  PoseErrArgs a; a.points = points; a.rvec_gt = rvec_gt; a.t_gt = t_gt; a.rvec_pr = rvec_pred; a.t_pr = t_pred;
+  a.add = add; a.add_s = add_s; a.P = num_points; a.D = num_pairs; a.max_points = max_points;
+  launch_pose_errors(a, (hipStream_t)stream);
+  HIPRET(hipGetLastError());
+  return 0;
+}
+
+int hep_pose_errors(int device, const float* points, int num_points, const float* rvec_gt, const float* t_gt, const float* rvec_pred,
+                    const float* t_pred, int num_pairs, int max_points, double* add, double* add_s) {
+  if (!points || !rvec_gt || !t_gt || !rvec_pred || !t_pred || !add || !add_s) return fail(HEP_ERR_INVALID, "bad argument");
+  if (num_points < 1 || num_pairs < 0) return fail(HEP_ERR_INVALID, "num_points must be >= 1 and num_pairs >= 0");
+  if (num_pairs == 0) return 0;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(HEP_ERR_DEVICE, "no HIP device visible: libhep has no CPU fallback");
+  if (device < 0 || device >= ndev) return fail(HEP_ERR_INVALID, "device index out of range");
+  HIPRET(hipSetDevice(device));
+  const size_t pb = (size_t)num_points * 12, db = (size_t)num_pairs * 12, ob = (size_t)num_pairs * 8;
+  unsigned char* buf = nullptr;
+  HIPRET(hipMalloc((void**)&buf, pb + 4 * db + 2 * ob + 64));
+  struct Free { unsigned char* p; ~Free() { hipFree(p); } } guard{buf};
+  float* d_pts = (float*)buf; float* d_rg = (float*)(buf + pb); float* d_tg = d_rg + 3 * num_pairs; float* d_rp = d_tg + 3 * num_pairs; float* d_tp = d_rp + 3 * num_pairs;
+  double* d_add = (double*)(buf + ((pb + 4 * db + 7) & ~(size_t)7)); double* d_adds = d_add + num_pairs;
+  HIPRET(hipMemcpy(d_pts, points, pb, hipMemcpyHostToDevice));
+  HIPRET(hipMemcpy(d_rg, rvec_gt, db, hipMemcpyHostToDevice)); HIPRET(hipMemcpy(d_tg, t_gt, db, hipMemcpyHostToDevice));
+  HIPRET(hipMemcpy(d_rp, rvec_pred, db, hipMemcpyHostToDevice)); HIPRET(hipMemcpy(d_tp, t_pred, db, hipMemcpyHostToDevice));
+  if (int rc = hep_pose_errors_device(d_pts, num_points, d_rg, d_tg, d_rp, d_tp, num_pairs, max_points, d_add, d_adds, nullptr)) return rc;
+  HIPRET(hipMemcpy(add, d_add, ob, hipMemcpyDeviceToHost));
+  HIPRET(hipMemcpy(add_s, d_adds, ob, hipMemcpyDeviceToHost));
   return 0;
 }
 

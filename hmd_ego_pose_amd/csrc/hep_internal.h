@@ -110,8 +110,8 @@ struct DecodeArgs {
   int B, N; float clip_max;
 };
 
-// ---- preprocess (no-resize case): uint8 RGB HWC -> normalised float32 HWC, zero-padded to S x S ----
-struct PreprocArgs { const uint8_t* in; float* out; int B, H, W, S; };
+// ---- preprocess: uint8 RGB HWC -> (8-bit bilinear resize to nh x nw) -> normalised float32 HWC, zero-padded to S x S ----
+struct PreprocArgs { const uint8_t* in; float* out; int B, H, W, S, nh, nw, resize; double inv_scale_x, inv_scale_y; };
 
 // ---- feature export: NHWC dtype -> NCHW fp32 ----
 struct ExportArgs { const void* in; float* out; int B, H, W, C, bf16; };
@@ -125,6 +125,16 @@ struct FilterArgs {
   float* det_boxes; float* det_scores; int32_t* det_labels; float* det_rotation; float* det_translation;
   float* det_hand; int32_t* det_index; int32_t* det_count;
 };
+
+// ---- pose errors: ADD / ADD-S of D pose pairs over P model points (eval/common.py:682-746) ----
+struct PoseErrArgs {
+  const float* points;                       // [P,3]
+  const float* rvec_gt; const float* t_gt;   // [D,3] axis-angle (radians), [D,3]
+  const float* rvec_pr; const float* t_pr;
+  double* add; double* add_s;                // [D]
+  int P, D, max_points;                      // max_points: 1000 in the reference (ADD-S subsampling)
+};
+void launch_pose_errors(const PoseErrArgs&, hipStream_t);
 
 void launch_stem(const StemArgs&, hipStream_t);
 void launch_pw(const PwArgs&, hipStream_t);

@@ -168,12 +168,30 @@ void launch_filter(const FilterArgs& a, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// preprocess_image for images that need no resize (reference generators/colibri_common.py:622-656 with
-// scale == 1, i.e. max(H, W) == network size - every 256x256 syn_colibri frame): uint8 RGB [B,H,W,3] ->
-// float32 [B,S,S,3], `image.astype(float32); image /= 255.; image -= mean; image /= std`, zero-padded at the
-// bottom / right.  numpy evaluates the two in-place operations with the float64 lists in double and rounds
-// the result to float32 each time; the kernel does exactly that, so the output is bit-identical.
+// preprocess_image (reference generators/colibri_common.py:622-656): uint8 RGB [B,H,W,3] ->
+//   cv2.resize(image, (resized_width, resized_height)) with scale = S / max(H, W), the longer side = S and the
+//   shorter one int(side * scale)                                                (skipped when scale == 1)
+//   image.astype(float32); image /= 255.; image -= mean; image /= std            (numpy evaluates the two in-place
+//   operations with the float64 lists in double and rounds to float32 each time: done exactly so here - the
+//   no-resize output is bit-identical to numpy's)
+//   zero-pad at the bottom / right to S x S
+// The resize is OpenCV's 8-bit INTER_LINEAR as documented in its source (imgproc/resize.cpp, restated from memory:
+// cv2 is not in this image, so this convention is PARITY-UNPINNED and stated in DESIGN.md): with an explicit output
+// size the per-axis inverse scale is src / dst; source coordinate of output x: fx = (float)((x + 0.5) * (W / nw) - 0.5),
+// sx = floor(fx), fx -= sx, clamped at the borders with the weight of the missing tap set to zero; weights as
+// shorts round(w * 2048); horizontal pass in int32 (src[sx]*a0 + src[sx+1]*a1), vertical pass
+// (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2.
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void resize_tap(int o, double inv_scale, int n, int* s0, int* s1, int* w0, int* w1) {
+  float f = (float)(((double)o + 0.5) * inv_scale - 0.5);
+  int i = (int)floorf(f);
+  f -= (float)i;
+  if (i < 0) { f = 0.f; i = 0; }
+  if (i >= n - 1) { f = 0.f; i = n - 1; }
+  *s0 = i; *s1 = min(i + 1, n - 1);
+  *w0 = (int)lrintf((1.f - f) * 2048.f); *w1 = (int)lrintf(f * 2048.f);
+}
+
 __global__ __launch_bounds__(256) void preprocess_kernel(PreprocArgs a) {
   const int64_t total = (int64_t)a.B * a.S * a.S * 3;
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -182,9 +200,20 @@ __global__ __launch_bounds__(256) void preprocess_kernel(PreprocArgs a) {
   const int64_t p = idx / 3;
   const int x = (int)(p % a.S), y = (int)((p / a.S) % a.S), b = (int)(p / ((int64_t)a.S * a.S));
   float v = 0.f;
-  if (y < a.H && x < a.W) {
+  if (y < a.nh && x < a.nw) {
+    const uint8_t* img = a.in + (int64_t)b * a.H * a.W * 3 + c;
+    int u8;
+    if (!a.resize) u8 = img[((int64_t)y * a.W + x) * 3];
+    else {
+      int x0, x1, a0, a1, y0, y1, b0, b1;
+      resize_tap(x, a.inv_scale_x, a.W, &x0, &x1, &a0, &a1);
+      resize_tap(y, a.inv_scale_y, a.H, &y0, &y1, &b0, &b1);
+      const int S0 = img[((int64_t)y0 * a.W + x0) * 3] * a0 + img[((int64_t)y0 * a.W + x1) * 3] * a1;
+      const int S1 = img[((int64_t)y1 * a.W + x0) * 3] * a0 + img[((int64_t)y1 * a.W + x1) * 3] * a1;
+      u8 = min(255, max(0, (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2));
+    }
     const double mean[3] = {0.485, 0.456, 0.406}, sd[3] = {0.229, 0.224, 0.225};
-    const float r1 = __fdiv_rn((float)a.in[(((int64_t)b * a.H + y) * a.W + x) * 3 + c], 255.0f);
+    const float r1 = __fdiv_rn((float)u8, 255.0f);
     const float r2 = (float)((double)r1 - mean[c]);
     v = (float)((double)r2 / sd[c]);
   }

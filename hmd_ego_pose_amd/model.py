@@ -90,9 +90,10 @@ class Session:
         return (tuple(feats) if feats else None, *outs)
 
     def preprocess(self, images_u8: torch.Tensor) -> torch.Tensor:
-        """uint8 RGB [B,H,W,3] on the device with max(H, W) == size -> the NCHW view of the normalised, zero-padded
-        float32 [B,size,size,3] (generators/colibri_common.py:622-656; the view is what eval/common.py:397 feeds
-        the model and ``forward`` reads in place).  Frames that would need a resize are refused."""
+        """uint8 RGB [B,H,W,3] on the device -> the NCHW view of the normalised, zero-padded float32 [B,size,size,3]
+        (generators/colibri_common.py:622-656; the view is what eval/common.py:397 feeds the model and ``forward``
+        reads in place).  Frames whose longer side is not ``size`` are resized on the GPU (8-bit bilinear, OpenCV's
+        convention restated - parity unpinned); the camera vector's image_scale is then size / max(H, W)."""
         if not images_u8.is_cuda or images_u8.dtype != torch.uint8 or images_u8.dim() != 4 or images_u8.shape[3] != 3:
             raise ValueError("expected a uint8 ROCm tensor [B,H,W,3]")
         x = images_u8.contiguous()

@@ -21,6 +21,9 @@
  *                                 (C# twins Program.cs:225-470)
  *   hep_filter / _device       <- FilterDetections / filter_detections, pytorch-sandbox/hmdegopose/layers.py:264-482
  *                                 (C# twin Program.cs:472-627)
+ *   hep_pose_errors / _device  <- check_6d_pose_add / check_6d_pose_add_s, pytorch-sandbox/eval/common.py:682-746 with
+ *                                 c_min_distances, pytorch-sandbox/generators/utils/calc_min_distances.h:24-35 (the
+ *                                 metric arithmetic of evaluate.py's loop, eval/common.py:866-1121)
  *
  * Conventions: plain pointers and sizes only; every function returns 0 on success or a
  * negative hep_status, never throws and never aborts; hep_last_error() gives a thread-local
@@ -136,12 +139,25 @@ int hep_filter_device(hep_handle* h, const float* boxes, const float* classifica
                       int32_t* det_labels, float* det_rotation, float* det_translation, float* det_hand,
                       int32_t* det_index, int32_t* det_count, void* stream);
 
-/* preprocess_image for frames that need no resize (reference generators/colibri_common.py:622-656 with
- * max(height, width) == size, i.e. scale 1.0 - every 256x256 syn_colibri frame): device uint8 RGB
- * [batch, height, width, 3] -> device float32 [batch, size, size, 3] = ((x / 255) - mean) / std, zero-padded at
- * the bottom / right, bit-identical to the numpy code.  Hand the result to hep_run_device as the NCHW view of
- * NHWC memory (strides {size*size*3, 1, size*3, 3}), exactly what eval/common.py:397 does.  Other sizes need
- * cv2.resize (bilinear on uint8: parity unpinned) and are refused with HEP_ERR_UNSUPPORTED. */
+/* ADD and ADD-S of num_pairs (ground truth, prediction) poses over one object model: points [num_points,3]; rotations
+ * as axis-angle vectors in radians (what _get_detections hands on: network output * pi), translations in the model's
+ * unit.  add[i] = mean over ALL points of ||(R_gt p + t_gt) - (R_pr p + t_pr)|| (float64); add_s[i] = mean over the
+ * ground-truth cloud subsampled with step = num_points / max_points + 1 (max_points = 1000 in the reference) of the
+ * float32 distance to the nearest point of the equally subsampled predicted cloud.  A pose counts as correct when the
+ * value is <= 0.1 * diameter (the caller's comparison).  The host variant copies through a temporary device buffer. */
+int hep_pose_errors(int device, const float* points, int num_points, const float* rvec_gt, const float* t_gt,
+                    const float* rvec_pred, const float* t_pred, int num_pairs, int max_points, double* add, double* add_s);
+int hep_pose_errors_device(const float* points, int num_points, const float* rvec_gt, const float* t_gt,
+                           const float* rvec_pred, const float* t_pred, int num_pairs, int max_points, double* add,
+                           double* add_s, void* stream);
+
+/* preprocess_image (reference generators/colibri_common.py:622-656): device uint8 RGB [batch, height, width, 3] ->
+ * device float32 [batch, size, size, 3]: resize by scale = size / max(height, width) (8-bit bilinear, OpenCV
+ * INTER_LINEAR fixed-point convention - restated, parity unpinned: cv2 is absent here; skipped when scale == 1, every
+ * 256x256 syn_colibri frame), then ((x / 255) - mean) / std with numpy's float64 intermediate steps (the no-resize
+ * output is bit-identical to the numpy code), zero-padded at the bottom / right.  Hand the result to hep_run_device as
+ * the NCHW view of NHWC memory (strides {size*size*3, 1, size*3, 3}), exactly what eval/common.py:397 does; the camera
+ * vector's image_scale entry is size / max(height, width). */
 int hep_preprocess_u8_device(hep_handle* h, const uint8_t* rgb_hwc, int batch, int height, int width,
                              float* out_hwc, void* stream);
 

@@ -188,24 +188,86 @@ def add_s_metric(points, diameter, R_gt, t_gt, R_pr, t_pr, thr=0.1, max_points=1
     g = (points @ R_gt.T + t_gt)
     p = (points @ R_pr.T + t_pr)
     step = points.shape[0] // max_points + 1
-    g = g[::step].astype(np.float32)
-    p = p[::step].astype(np.float32)
-    diff = g[:, None, :] - p[None, :, :]
-    d2 = (diff[..., 0] * diff[..., 0] + diff[..., 1] * diff[..., 1]) + diff[..., 2] * diff[..., 2]
-    dmin = np.sqrt(d2.astype(np.float64)).astype(np.float32).min(axis=1)
+    dmin = min_distances(g[::step], p[::step])
     d = float(np.mean(dmin))
     return d <= diameter * thr, d
 
 
+def reference_min_distances(points_gt: np.ndarray, points_pred: np.ndarray) -> np.ndarray:
+    """The REAL reference: c_min_distances of generators/utils/calc_min_distances.h compiled by oracle/Makefile into
+    oracle/_ref/libmindist.so (called like wrapper_c_min_distances, compute_overlap.pyx:103-121: both clouds cast to
+    C-contiguous float32).  Raises FileNotFoundError when the library has not been built."""
+    import ctypes
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", "libmindist.so")
+    if not os.path.exists(path):
+        raise FileNotFoundError(path + " (run `make -C oracle` where /root/reference is present)")
+    lib = ctypes.CDLL(path)
+    g = np.ascontiguousarray(points_gt, dtype=np.float32)
+    p = np.ascontiguousarray(points_pred, dtype=np.float32)
+    out = np.zeros((g.shape[0],), dtype=np.float32)
+    fp = ctypes.POINTER(ctypes.c_float)
+    lib.c_min_distances.argtypes = [fp, fp, fp, ctypes.c_int, ctypes.c_int]
+    lib.c_min_distances.restype = None
+    lib.c_min_distances(g.ctypes.data_as(fp), p.ctypes.data_as(fp), out.ctypes.data_as(fp), g.shape[0], p.shape[0])
+    return out
+
+
+def min_distances(points_gt: np.ndarray, points_pred: np.ndarray) -> np.ndarray:
+    """numpy restatement of c_min_distances (calc_min_distances.h:24-35): float32 differences, products and sums in the
+    C order ((d1*d1 + d2*d2) + d3*d3), (float) sqrt((double) .), minimum over the predicted cloud.  Pinned bit for bit
+    against the compiled reference (tests/test_decode_oracle_cpu.py)."""
+    g = np.ascontiguousarray(points_gt, dtype=np.float32)
+    p = np.ascontiguousarray(points_pred, dtype=np.float32)
+    diff = g[:, None, :] - p[None, :, :]
+    d2 = (diff[..., 0] * diff[..., 0] + diff[..., 1] * diff[..., 1]) + diff[..., 2] * diff[..., 2]
+    return np.sqrt(d2.astype(np.float64)).astype(np.float32).min(axis=1)
+
+
+def resize_bilinear_u8(image: np.ndarray, nw: int, nh: int) -> np.ndarray:
+    """cv2.resize(image, (nw, nh)) for uint8 HWC, INTER_LINEAR, as OpenCV's 8-bit fixed-point path is written
+    (imgproc/resize.cpp; restated from its source, cv2 is not in this image: PARITY UNPINNED): with an explicit size the
+    per-axis inverse scale is src / dst; fx = float32((dx + 0.5) * (w / nw) - 0.5), sx = floor(fx), fx -= sx, border
+    taps clamped with zero weight; weights as int round(w * 2048); horizontal pass in int32, vertical pass
+    (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2."""
+    h, w = image.shape[:2]
+
+    def taps(n_out, n_in):
+        inv = n_in / n_out
+        f = ((np.arange(n_out, dtype=np.float64) + 0.5) * inv - 0.5).astype(np.float32)
+        i = np.floor(f).astype(np.int64)
+        f = f - i.astype(np.float32)
+        lo, hi = i < 0, i >= n_in - 1
+        f = np.where(lo | hi, np.float32(0), f)
+        i = np.where(lo, 0, np.where(hi, n_in - 1, i))
+        w1 = np.rint(f * np.float32(2048)).astype(np.int64)
+        w0 = np.rint((np.float32(1) - f) * np.float32(2048)).astype(np.int64)
+        return i, np.minimum(i + 1, n_in - 1), w0, w1
+
+    x0, x1, a0, a1 = taps(nw, w)
+    y0, y1, b0, b1 = taps(nh, h)
+    src = image.astype(np.int64)
+    S = src[:, x0, :] * a0[None, :, None] + src[:, x1, :] * a1[None, :, None]            # [h, nw, 3]
+    out = (((b0[:, None, None] * (S[y0] >> 4)) >> 16) + ((b1[:, None, None] * (S[y1] >> 4)) >> 16) + 2) >> 2
+    return np.clip(out, 0, 255).astype(np.uint8)
+
+
 def preprocess_image(image: np.ndarray, image_size: int):
-    """generators/colibri_common.py:622-656 for frames that need no resize (max(H, W) == image_size, scale 1.0:
-    cv2.resize to the same size returns the image unchanged).  The arithmetic lines are the reference's own:
-    uint8 HWC RGB -> float32, /255., -mean, /std (numpy evaluates the two list operands in float64 and rounds
-    the in-place result to float32), zero-pad bottom/right.  Returns (image [S,S,3] float32, scale)."""
+    """generators/colibri_common.py:622-656.  Frames with max(H, W) == image_size need no resize (scale 1.0: cv2.resize
+    to the same size returns the image unchanged; that branch is pinned against the imported reference function,
+    tests/golden/preprocess.npz); others go through ``resize_bilinear_u8`` (parity unpinned).  The arithmetic lines are
+    the reference's own: uint8 HWC RGB -> float32, /255., -mean, /std (numpy evaluates the two list operands in float64
+    and rounds the in-place result to float32), zero-pad bottom/right.  Returns (image [S,S,3] float32, scale)."""
     image_height, image_width = image.shape[:2]
-    if max(image_height, image_width) != image_size:
-        raise ValueError("resize needed: cv2.resize (bilinear, uint8) is parity-unpinned and not restated")
-    scale = image_size / max(image_height, image_width)
+    if image_height > image_width:
+        scale = image_size / image_height
+        resized_height, resized_width = image_size, int(image_width * scale)
+    else:
+        scale = image_size / image_width
+        resized_height, resized_width = int(image_height * scale), image_size
+    if (resized_height, resized_width) != (image_height, image_width):
+        image = resize_bilinear_u8(image, resized_width, resized_height)
+        image_height, image_width = resized_height, resized_width
     image = image.astype(np.float32)
     image /= 255.
     mean = [0.485, 0.456, 0.406]

@@ -51,3 +51,54 @@ def check_digest(name, arr, info, ref_slice, stride, atol, rtol=0.0):
     assert abs(sa - info["abssum"]) <= n * atol + rtol * info["abssum"] + 1e-6, (name, sa, info["abssum"])
     assert abs(s - info["sum"]) <= n * atol + rtol * info["abssum"] + 1e-6, (name, s, info["sum"])
     return float(err.max())
+
+
+def make_linemod_folder(root, n=5, size=256, seed=0, binary_ply=True):
+    """A tiny synthetic dataset in the Linemod layout the reference's ColibriGenerator reads (data/01/{rgb,mask}/*.png,
+    gt_0.yml, info_0.yml, test_0.txt, models/obj_01.ply, models_info.yml).  Returns the ground truth it wrote."""
+    import os
+    import yaml
+    from PIL import Image
+    from scipy.spatial.transform import Rotation
+    rng = np.random.Generator(np.random.PCG64(seed))
+    obj = os.path.join(root, "data", "01")
+    for d in ("rgb", "mask"):
+        os.makedirs(os.path.join(obj, d), exist_ok=True)
+    os.makedirs(os.path.join(root, "models"), exist_ok=True)
+    pts = (rng.standard_normal((1500, 3)) * np.array([40.0, 25.0, 60.0])).astype(np.float32)
+    with open(os.path.join(root, "models", "obj_01.ply"), "wb") as f:
+        if binary_ply:
+            f.write(b"ply\nformat binary_little_endian 1.0\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z\nproperty uchar red\nelement face 0\nproperty list uchar int vertex_indices\nend_header\n" % len(pts))
+            rec = np.zeros(len(pts), dtype=[("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("red", "u1")])
+            rec["x"], rec["y"], rec["z"] = pts[:, 0], pts[:, 1], pts[:, 2]
+            f.write(rec.tobytes())
+        else:
+            f.write(b"ply\nformat ascii 1.0\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z\nend_header\n" % len(pts))
+            for p in pts:
+                f.write(("%r %r %r\n" % (float(p[0]), float(p[1]), float(p[2]))).encode())
+    with open(os.path.join(root, "models", "models_info.yml"), "w") as f:
+        yaml.safe_dump({1: {"diameter": 180.0, "min_x": -100.0, "min_y": -80.0, "min_z": -150.0, "size_x": 200.0, "size_y": 160.0, "size_z": 300.0}}, f)
+    gt, info, names, truth = {}, {}, [], []
+    for i in range(n + 1):                        # one extra frame that is NOT in the split
+        img = rng.integers(0, 256, (size, size, 3), dtype=np.uint8)
+        Image.fromarray(img).save(os.path.join(obj, "rgb", f"{i:06d}.png"))
+        m = np.zeros((size, size), np.uint8)
+        x0, y0 = int(rng.integers(5, 100)), int(rng.integers(5, 100))
+        x1, y1 = x0 + int(rng.integers(30, 120)), y0 + int(rng.integers(30, 120))
+        m[y0:y1 + 1, x0:x1 + 1] = 255
+        Image.fromarray(m).save(os.path.join(obj, "mask", f"{i:06d}.png"))
+        R = Rotation.from_rotvec(rng.standard_normal(3)).as_matrix()
+        t = np.array([rng.normal(0, 40), rng.normal(0, 40), 500 + rng.normal(0, 50)])
+        gt[i] = [{"cam_R_m2c": [float(v) for v in R.reshape(-1)], "cam_t_m2c": [float(v) for v in t], "obj_bb": [x0, y0, x1 - x0, y1 - y0],
+                  "obj_id": 1, "drill_tip_transform": [10.0, -20.0, 30.0, 1.0]}]
+        info[i] = {"cam_K": [480.0, 0.0, 128.0, 0.0, 480.0, 128.0, 0.0, 0.0, 1.0], "depth_scale": 1.0}
+        if i < n:
+            names.append(f"{i:06d}")
+            truth.append(dict(image=img, bbox=np.array([x0, y0, x1, y1], np.float32), R=R, t=t))
+    with open(os.path.join(obj, "gt_0.yml"), "w") as f:
+        yaml.safe_dump(gt, f)
+    with open(os.path.join(obj, "info_0.yml"), "w") as f:
+        yaml.safe_dump(info, f)
+    with open(os.path.join(obj, "test_0.txt"), "w") as f:
+        f.write("\n".join(names) + "\n")
+    return pts, truth

@@ -116,5 +116,65 @@ def test_preprocess_image_restatement():
     assert np.array_equal(out[0, 0], ((np.float32(0) - mean).astype(np.float32) / std).astype(np.float32))
     assert np.array_equal(out[1, 2], ((np.float32(1) - mean).astype(np.float32) / std).astype(np.float32))
     assert not out[200:].any()
-    with pytest.raises(ValueError):
-        D.preprocess_image(np.zeros((100, 100, 3), np.uint8), 256)
+
+
+def test_min_distances_match_the_compiled_reference():
+    """oracle.min_distances (numpy) against c_min_distances of the reference's own calc_min_distances.h, compiled by
+    oracle/Makefile from where it lies under /root/reference (oracle/_ref/libmindist.so): bit for bit, on clouds with
+    close pairs, duplicates and large offsets; and add_s_metric's subsampling (step = n // 1000 + 1)."""
+    import os
+    so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "libmindist.so")
+    if not os.path.exists(so):
+        pytest.skip("oracle/_ref/libmindist.so not built (needs /root/reference: `make -C oracle`)")
+    rng = np.random.Generator(np.random.PCG64(5))
+    for n_g, n_p, scale, off in ((1, 1, 1.0, 0.0), (7, 13, 100.0, 0.0), (500, 500, 130.0, 2.5), (1000, 777, 0.05, 1000.0)):
+        g = (rng.standard_normal((n_g, 3)) * scale + off).astype(np.float32)
+        p = (rng.standard_normal((n_p, 3)) * scale + off).astype(np.float32)
+        if n_p > 10:
+            p[3] = g[min(2, n_g - 1)]                       # an exact hit
+            p[5] = p[4]                                    # duplicates
+        want = D.reference_min_distances(g, p)
+        got = D.min_distances(g, p)
+        assert got.dtype == np.float32 and np.array_equal(got, want), (n_g, n_p)
+    # the metric: 2500 model points -> step 3 -> 834 points per cloud
+    pts = (rng.standard_normal((2500, 3)) * 60).astype(np.float32)
+    Rg, Rp = D.rodrigues(np.array([0.3, -1.2, 0.5])), D.rodrigues(np.array([0.31, -1.18, 0.52]))
+    tg, tp = np.array([10., -20., 600.]), np.array([11., -19., 604.])
+    ok, d = D.add_s_metric(pts, 150.0, Rg, tg, Rp, tp)
+    ref = D.reference_min_distances((pts @ Rg.T + tg)[::3], (pts @ Rp.T + tp)[::3])
+    assert len(ref) == 834 and d == float(np.mean(ref)) and ok == (d <= 15.0)
+
+
+def test_preprocess_matches_the_imported_reference_and_resize_convention():
+    """oracle.preprocess_image, no-resize branch: bit-identical (sha256) to what the REAL reference function returned for
+    the same seeded frames (tests/golden/preprocess.npz, made by tests/golden/make_golden_preprocess.py with a cv2 stub
+    whose resize is the identity).  Resize branch (parity unpinned: OpenCV's 8-bit INTER_LINEAR restated): known answers
+    of the fixed-point convention - a constant image stays constant, x2 upsampling of a ramp interpolates at quarter
+    positions, sizes follow int(side * scale)."""
+    import hashlib
+    import os
+    import importlib.util
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("mgp", os.path.join(here, "golden", "make_golden_preprocess.py"))
+    mgp = importlib.util.module_from_spec(spec); spec.loader.exec_module(mgp)
+    fx = np.load(os.path.join(here, "golden", "preprocess.npz"))
+    for name, img, size in mgp.cases():
+        out, scale = D.preprocess_image(img, size)
+        assert scale == 1.0 and out.dtype == np.float32
+        assert hashlib.sha256(out.tobytes()).digest() == fx[name + "_sha256"].tobytes(), name
+        assert np.array_equal(out.reshape(-1)[::997], fx[name + "_slice"])
+    # resize convention
+    const = np.full((100, 128, 3), 77, np.uint8)
+    out, scale = D.preprocess_image(const, 256)
+    assert scale == 2.0 and out.shape == (256, 256, 3)
+    v = np.float32(np.float64(np.float32(np.float32(77) / np.float32(255.0))) - 0.485)
+    assert np.all(out[:200, :, 0] == np.float32(np.float64(v) / 0.229)) and np.all(out[200:] == 0)
+    ramp = np.tile((np.arange(8, dtype=np.uint8) * 16)[None, :, None], (8, 1, 3))
+    up = D.resize_bilinear_u8(ramp, 16, 16)
+    # output x samples source (x + 0.5) / 2 - 0.5: 0 -> clamped to 0, 1 -> 0.25 => 4, 2 -> 0.75 => 12, 3 -> 1.25 => 20 ...
+    assert up[0, :6, 0].tolist() == [0, 4, 12, 20, 28, 36] and up[0, -1, 0] == 112 and np.all(up[:, :, 1] == up[:, :, 0])
+    down = D.resize_bilinear_u8(np.tile(np.arange(16, dtype=np.uint8)[None, :, None] * 10, (4, 1, 3)), 8, 2)
+    assert down.shape == (2, 8, 3) and down[0, :3, 0].tolist() == [5, 25, 45]          # midpoints of pixel pairs
+    tall = np.zeros((300, 200, 3), np.uint8)
+    out, scale = D.preprocess_image(tall, 256)
+    assert abs(scale - 256 / 300) < 1e-15 and np.all(out[:, int(200 * scale):] == 0) and np.all(out[:, :int(200 * scale)] != 0)

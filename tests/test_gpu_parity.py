@@ -390,8 +390,9 @@ def test_inflight_pool_matches_single_session():
 
 
 def test_preprocess_is_bit_exact_and_feeds_the_forward(api):
-    """uint8 frames -> hep_preprocess_u8_device == the reference's numpy arithmetic bit for bit (no-resize case,
-    incl. bottom/right zero padding); its NHWC-memory NCHW view goes straight into the forward."""
+    """uint8 frames -> hep_preprocess_u8_device == the oracle's preprocess_image bit for bit (whose no-resize branch is
+    pinned to the imported reference, tests/golden/preprocess.npz), incl. bottom/right zero padding and the resize
+    branch; its NHWC-memory NCHW view goes straight into the forward."""
     size = 256
     s = api["Session"](api["sd"](0, 0), 0, size, 4, "fp32")
     rng = np.random.Generator(np.random.PCG64(11))
@@ -406,8 +407,14 @@ def test_preprocess_is_bit_exact_and_feeds_the_forward(api):
     b = s.forward(got.contiguous())
     for u, v in zip(a[1:], b[1:]):
         assert torch.equal(u, v)
-    with pytest.raises(api["capi"].HepError, match="preprocess"):
-        s.preprocess(torch.zeros((1, 128, 128, 3), dtype=torch.uint8, device="cuda"))
+    # frames that need a resize (8-bit bilinear, OpenCV's fixed-point convention as restated in the oracle: parity
+    # unpinned against cv2 itself, bit-identical between kernel and oracle): x2 up (128 -> 256), down (480x640 -> 192x256),
+    # odd sizes, tall frames
+    for (h, w) in ((128, 128), (480, 640), (97, 211), (300, 200)):
+        img = rng.integers(0, 256, (2, h, w, 3), dtype=np.uint8)
+        want = np.stack([api["D"].preprocess_image(f, size)[0] for f in img])
+        got = s.preprocess(torch.from_numpy(img).cuda())
+        assert np.array_equal(got.permute(0, 2, 3, 1).cpu().numpy(), want), (h, w)
     s.close()
 
 
@@ -546,3 +553,68 @@ def test_create_from_pack_file_and_bad_arguments(api, tmp_path):
     h2 = ctypes.c_void_p()
     assert lib.hep_create(str(tmp_path / "nope.hepw").encode(), phi, size, 1, capi.HEP_F32, 0, 0, ctypes.byref(h2)) == -2
     assert lib.hep_create(path.encode(), 3, 512, 1, capi.HEP_F32, 0, 0, ctypes.byref(h2)) == -2 and b"weight pack" in lib.hep_last_error()
+
+
+def test_pose_errors_match_oracle_and_compiled_reference(api):
+    """hep_pose_errors (ADD / ADD-S on the GPU) against the numpy oracle (eval/common.py:682-746) and, for the
+    nearest-point search, against the reference's own C code compiled into oracle/_ref (when present): ADD within 1e-9
+    relative (float64 on both sides, different summation order), ADD-S within 1e-6 relative (identical float32 minima,
+    the mean is taken in float64 here and in float32 pairwise by numpy)."""
+    from hmd_ego_pose_amd import evaluate as E
+    D = api["D"]
+    rng = np.random.Generator(np.random.PCG64(17))
+    for P in (1, 37, 999, 1000, 1001, 4321):
+        pts = (rng.standard_normal((P, 3)) * np.array([40.0, 25.0, 60.0])).astype(np.float32)
+        n = 6
+        rg, rp = rng.standard_normal((n, 3)).astype(np.float32), rng.standard_normal((n, 3)).astype(np.float32)
+        rp[0] = rg[0]; rp[1] = 0; rg[1] = 0                      # identical rotation; zero rotation (identity branch)
+        tg = (rng.standard_normal((n, 3)) * 30 + np.array([0, 0, 500.0])).astype(np.float32)
+        tp = tg + rng.standard_normal((n, 3)).astype(np.float32) * np.array([1, 1, 8], np.float32)
+        tp[0] = tg[0]
+        add, add_s = E.pose_errors(pts, rg, tg, rp, tp)
+        for i in range(n):
+            Rg, Rp = D.rodrigues(rg[i]), D.rodrigues(rp[i])
+            _, want = D.add_metric(pts.astype(np.float64), 100.0, Rg, tg[i].astype(np.float64), Rp, tp[i].astype(np.float64))
+            assert abs(add[i] - want) <= 1e-9 * max(1.0, want), (P, i, add[i], want)
+            _, want_s = D.add_s_metric(pts.astype(np.float64), 100.0, Rg, tg[i].astype(np.float64), Rp, tp[i].astype(np.float64))
+            assert abs(add_s[i] - want_s) <= 1e-6 * max(1.0, want_s), (P, i, add_s[i], want_s)
+            try:
+                step = P // 1000 + 1
+                ref = D.reference_min_distances((pts.astype(np.float64) @ Rg.T + tg[i])[::step], (pts.astype(np.float64) @ Rp.T + tp[i])[::step])
+                assert abs(add_s[i] - float(np.mean(ref.astype(np.float64)))) <= 1e-7 * max(1.0, want_s)
+            except FileNotFoundError:
+                pass
+        assert add[0] == 0.0 and add_s[0] == 0.0
+
+
+def test_evaluator_on_a_synthetic_linemod_folder(api, tmp_path):
+    """The evaluate.py replacement end to end (folder reader -> GPU preprocess -> forward -> decode -> filter ->
+    post-filter -> matching -> ADD / ADD-S on the GPU): its metrics equal an independent recomputation with the oracle's
+    numpy functions from the detections it reports."""
+    from hmd_ego_pose_amd import HMDEgoPose, TrainModelWithLoss
+    from hmd_ego_pose_amd import evaluate as E
+    from tests._util import make_linemod_folder
+    D = api["D"]
+    make_linemod_folder(str(tmp_path / "ds"), n=5)
+    ds = E.LinemodFolder(str(tmp_path / "ds"))
+    m = HMDEgoPose({"iter": 0}, num_classes=1, compound_coef=0, onnx_export=True, input_sizes=[256] * 9)
+    m.load_state_dict(api["sd"](0, 0), strict=True)
+    model = TrainModelWithLoss(m.to("cuda").eval()).eval()
+    dets = []
+    res = E.evaluate(ds, model, 256, score_threshold=0.5, max_detections=10, iou_threshold=0.05, batch_size=3, detections_out=dets)
+    assert len(dets) == 5 and res["num_annotations"] == 5.0
+    # independent recomputation
+    n_ok_add = n_ok_adds = matched = 0
+    for i, (boxes, sc, _l, rots, trans, _h) in enumerate(dets):
+        assert boxes.shape[0] <= 10 and np.all(sc > 0.5) and np.all(np.diff(sc) <= 0)
+        ann = ds.annotations[i]
+        for d in range(boxes.shape[0]):
+            if E.compute_overlap(boxes[d:d + 1], ann["bbox"][None])[0, 0] >= 0.05:
+                matched += 1
+                Rg, Rp = D.rodrigues(ann["rotation"].astype(np.float32)), D.rodrigues(rots[d])
+                ok, _ = D.add_metric(ds.points.astype(np.float64), ds.diameter, Rg, ann["translation"].astype(np.float32).astype(np.float64), Rp, trans[d].astype(np.float64))
+                ok_s, _ = D.add_s_metric(ds.points.astype(np.float64), ds.diameter, Rg, ann["translation"].astype(np.float32).astype(np.float64), Rp, trans[d].astype(np.float64))
+                n_ok_add += ok; n_ok_adds += ok_s
+                break
+    assert res["num_matched"] == matched
+    assert res["ADD"] == n_ok_add / 5 and res["ADD-S"] == n_ok_adds / 5 and 0.0 <= res["AP"] <= 1.0

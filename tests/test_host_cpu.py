@@ -3,6 +3,7 @@ library's exports and its host-only entry points, the nn.Module drop-in's state_
 contract and its loud refusal to run without a ROCm device."""
 import ctypes
 import hashlib
+import math
 import os
 import re
 
@@ -147,3 +148,43 @@ def test_corrupt_pack_is_refused_without_reading_out_of_bounds():
         h = ctypes.c_void_p()
         rc = l.hep_create_from_memory(blob, len(blob), 0, 256, 1, _capi.HEP_F32, 0, 0, ctypes.byref(h))
         assert rc == -2 and b"weight pack" in l.hep_last_error(), (dims, off, nb, rc, l.hep_last_error())
+
+
+def test_evaluator_host_logic(tmp_path):
+    """hmd_ego_pose_amd.evaluate without a GPU: the Linemod-folder reader (binary and ASCII PLY, yml, split file, mask
+    boxes), Rodrigues both ways against scipy, IoU with the +1 convention, AP, and the post-filter (a15) against the
+    oracle's restatement of eval/common.py:419-447."""
+    from scipy.spatial.transform import Rotation
+    from hmd_ego_pose_amd import evaluate as E
+    from oracle import decode_ref as D
+    from tests._util import make_linemod_folder
+    pts, truth = make_linemod_folder(str(tmp_path / "ds"), n=4)
+    ds = E.LinemodFolder(str(tmp_path / "ds"))
+    assert len(ds) == 4 and ds.diameter == 180.0 and np.array_equal(ds.points, pts)
+    for i, t in enumerate(truth):
+        assert np.array_equal(ds.load_image(i), t["image"]) and np.array_equal(ds.annotations[i]["bbox"], t["bbox"])
+        assert np.allclose(E.axis_angle_to_matrix(ds.annotations[i]["rotation"]), t["R"], atol=1e-12)
+        assert np.allclose(ds.annotations[i]["translation"], t["t"])
+        assert ds.camera_input(i, 1.0).tolist() == [480.0, 480.0, 128.0, 128.0, 1000.0, 1.0]
+    pts2, _ = make_linemod_folder(str(tmp_path / "ds2"), n=1, binary_ply=False)
+    assert np.array_equal(E.LinemodFolder(str(tmp_path / "ds2")).points, pts2)
+    rng = np.random.Generator(np.random.PCG64(3))
+    for rv in list(rng.standard_normal((20, 3))) + [np.array([math.pi - 1e-8, 0, 0]), np.array([0.0, 0.0, 0.0]), np.array([1e-11, 0, 0]), np.array([0, 2.0, 0])]:
+        R = Rotation.from_rotvec(rv).as_matrix()
+        assert np.allclose(E.axis_angle_to_matrix(rv), R, atol=1e-12) and np.allclose(E.axis_angle_to_matrix(rv), D.rodrigues(rv), atol=1e-15)
+        back = E.matrix_to_axis_angle(R)
+        assert np.allclose(E.axis_angle_to_matrix(back), R, atol=1e-9), rv
+    # IoU, +1 convention: identical boxes 1.0; [0,0,9,9] vs [5,5,14,14]: 25 / (100 + 100 - 25)
+    ov = E.compute_overlap(np.array([[0, 0, 9, 9], [20, 20, 30, 30]], float), np.array([[0, 0, 9, 9], [5, 5, 14, 14]], float))
+    assert ov[0, 0] == 1.0 and abs(ov[0, 1] - 25 / 175) < 1e-15 and ov[1, 0] == 0.0
+    assert abs(E.compute_ap(np.array([0.5, 0.5, 1.0]), np.array([1.0, 0.5, 2 / 3])) - (0.5 * 1.0 + 0.5 * 2 / 3)) < 1e-15
+    # post-filter
+    M = 8
+    det = {"boxes": torch.arange(M * 4, dtype=torch.float32).reshape(M, 4), "scores": torch.tensor([0.9, 0.3, 0.7, 0.7, 0.06, 0.04, -1.0, -1.0]),
+           "labels": torch.tensor([0, 0, 0, 0, 0, 0, -1, -1], dtype=torch.int32), "rotation": torch.linspace(-1, 1, M * 3).reshape(M, 3),
+           "translation": torch.randn(M, 3), "hand": torch.randn(M, 63)}
+    b, s_, _l, r, t, _h = E.post_filter(det, 0.8, 0.05, 4)
+    ob, os_, orr, ot = D.post_filter(det["boxes"].numpy(), det["scores"].numpy(), det["rotation"].numpy(), det["translation"].numpy(), 0.8, 0.05, 4)
+    assert s_.tolist() == [np.float32(0.9), np.float32(0.7), np.float32(0.7), np.float32(0.3)]
+    assert np.array_equal(b, ob) and np.array_equal(s_, os_) and np.array_equal(r, orr) and np.array_equal(t, ot)
+    assert np.array_equal(b[1], det["boxes"][2].numpy() / np.float32(0.8))         # equal scores: lower row first
