@@ -183,6 +183,7 @@ void launch_filter(const FilterArgs& a, hipStream_t s) {
 // (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void resize_tap(int o, double inv_scale, int n, int* s0, int* s1, int* w0, int* w1) {
+#pragma clang fp contract(off)      // OpenCV (and the oracle) round the product before subtracting 0.5
   float f = (float)(((double)o + 0.5) * inv_scale - 0.5);
   int i = (int)floorf(f);
   f -= (float)i;
