@@ -45,11 +45,12 @@ struct TensorDesc {
   void* ext_ptr = nullptr;
 };
 
-enum OpKind { OP_STEM, OP_PW, OP_DW, OP_POOL, OP_SEP, OP_MBF, OP_PWG };
+enum OpKind { OP_STEM, OP_PW, OP_DW, OP_POOL, OP_SEP, OP_MBF, OP_PWG, OP_CHAIN };
 struct Op {
   OpKind kind; std::string name;
-  StemArgs stem; PwArgs pw; DwArgs dw; PoolArgs pool; SepArgs sep; MbfArgs mbf; PwgArgs pwg;
+  StemArgs stem; PwArgs pw; DwArgs dw; PoolArgs pool; SepArgs sep; MbfArgs mbf; PwgArgs pwg; ChainArgs chain;
   std::vector<SepSeg> segs;         // host copy (device copy uploaded at build)
+  std::vector<ChainNode> cnodes;    // host copy of a chain's node table
   std::vector<int> reads, writes;   // tensor ids
   double act_bytes_per_image = 0, flops_per_image = 0, weight_bytes = 0;
 };

@@ -103,6 +103,27 @@ struct SepArgs {
   size_t off_atile, off_wdw, off_bias, lds_bytes;   // LDS layout (k_sep.hip: sep_lds_layout)
 };
 
+// ---- LDS-resident chain of small-level BiFPN nodes, one workgroup per image (k_chain.hip, bf16 sessions) ----
+#define CH_MAX_NODES 8
+#define CH_MAX_EXT 8
+struct ChainSrc { int off, kind, sh, sw; float fw; };    // LDS slot (element offset) holding the source map at sh x sw; kind relative to the node's size
+struct ChainNode {
+  ChainSrc src[HEP_MAX_SRC]; int nsrc, h, w, pool_only, pool_pad;
+  int out_off; int widx; void* out;                      // LDS slot and global map of the result [B][h*w][C]; widx: index of its weights in the blob
+};
+struct ChainExt {                                        // an input map produced by an earlier launch
+  const void* src; void* store;                          // store: the pooled map is also written here (p6_in of cell 0), else NULL
+  int sh, sw, kind, h, w, pool_pad, off;                 // kind SRC_DOWN: pooled to h x w while it is loaded; else copied (h x w == sh x sw)
+};
+struct ChainArgs {
+  const ChainNode* nodes; const void* wblob;             // device: node table, the nodes' weights in LDS layout
+  ChainExt ext[CH_MAX_EXT];
+  int nnodes, nconv, next, B, C, wnode_bytes;           // nconv: nodes with a convolution (the others are plain max-pools)
+  size_t off_w, off_halo, off_atile, lds_bytes;
+};
+void launch_chain(const ChainArgs&, hipStream_t);
+int chain_prepare(void);
+
 // ---- decode: boxes + translation from raw heads (loss.py:12-51) ----
 struct DecodeArgs {
   const float* regression; const float* translation_raw; const float* camera;

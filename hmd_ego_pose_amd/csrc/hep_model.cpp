@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <functional>
+#include <map>
 
 #include "hep.h"
 #include "hep_host.h"
@@ -228,7 +229,7 @@ static bool fold_bn(const Pack& pk, const std::string& p, int c, BnFold* out, st
 struct Ref { int op; int field; int seg; int idx; size_t woff; int tensor; };
 enum { F_STEM_W, F_STEM_B, F_STEM_OUT, F_PW_A, F_PW_W, F_PW_B, F_PW_RES, F_PW_OUT, F_DW_IN, F_DW_W, F_DW_B,
        F_DW_OUT, F_DW_PART, F_DW_WR, F_MBF_IN, F_MBF_WE, F_MBF_BE, F_MBF_WDW, F_MBF_BDW, F_MBF_OUT, F_MBF_PART, F_MBF_WR, F_MBF_WESCALE, F_PW_WSCALE, F_PW_HPART, F_PW_SEBR, F_PW_SEWE, F_PW_SEBE, F_POOL_IN, F_POOL_OUT, F_PWG_A, F_PWG_W, F_PWG_B, F_PWG_OUT,
-       F_SEG_SRC, F_SEG_WDW, F_SEG_WPW, F_SEG_BIAS, F_SEG_OUT };
+       F_SEG_SRC, F_SEG_WDW, F_SEG_WPW, F_SEG_BIAS, F_SEG_OUT, F_CH_EXT_SRC, F_CH_EXT_STORE, F_CH_NODE_OUT, F_CH_WBLOB };
 
 struct Planner {
   Session* s; const Pack& pk; std::string* err; WBuilder wb; bool ok = true;
@@ -255,7 +256,7 @@ struct Planner {
   }
   int new_op(OpKind k, const std::string& name) {
     Op o; memset(&o.stem, 0, sizeof o.stem); memset(&o.pw, 0, sizeof o.pw); memset(&o.dw, 0, sizeof o.dw);
-    memset(&o.pool, 0, sizeof o.pool); memset(&o.sep, 0, sizeof o.sep); memset(&o.mbf, 0, sizeof o.mbf); memset(&o.pwg, 0, sizeof o.pwg);
+    memset(&o.pool, 0, sizeof o.pool); memset(&o.sep, 0, sizeof o.sep); memset(&o.mbf, 0, sizeof o.mbf); memset(&o.pwg, 0, sizeof o.pwg); memset(&o.chain, 0, sizeof o.chain);
     o.kind = k; o.name = name;
     s->ops.push_back(o);
     return (int)s->ops.size() - 1;
@@ -406,7 +407,8 @@ struct Planner {
     // nothing) and loses on the big early maps (bandwidth-bound, the two-kernel path already streams well;
     // stride-2 halos there cost up to 4.5x recompute).  HEP_MBF=all|none overrides for A/B runs.
     const char* mode = getenv("HEP_MBF");
-    const bool want = mode ? !strcmp(mode, "all") : Hin <= 32;
+    static const int maxh = getenv("HEP_MBF_MAXH") ? atoi(getenv("HEP_MBF_MAXH")) : 32;     // A/B knob: largest input map that takes the fused front
+    const bool want = mode ? !strcmp(mode, "all") : Hin <= maxh;
     if (want && !(mode && !strcmp(mode, "none")))
       for (int cand : {64, 32, 16})
         if (mbf_lds_layout(b.cin, std::min(cand, b.expand ? cand : b.cexp), b.k, b.stride, s->dtype, b.expand, max_in, ts, nullptr) <= 159 * 1024) { CC = cand; break; }
@@ -626,6 +628,115 @@ struct Planner {
     if (o.sep.lds_bytes > 160 * 1024) { *err = "BiFPN width too large for the fused separable-conv tile"; ok = false; return; }
     o.act_bytes_per_image = bytes; o.flops_per_image = flops; o.weight_bytes = wbytes;
   }
+
+  // ---- LDS-resident chain of small-level BiFPN nodes (k_chain.hip): [optional max-pools of cell 0] + nodes ----
+  // pools: {source tensor, output tensor, output level} in order (cell 0: p6_in from p6_pre, p7_in from p6_in).
+  // Returns false (nothing added) when the chain does not fit the kernel: the caller then emits the k_sep.hip path.
+  struct PoolSpec { int src_t, out_t, level; };
+  bool add_chain(const std::string& name, const std::vector<PoolSpec>& pools, const std::vector<SegSpec>& specs) {
+    const int C = s->arch.fpn_w;
+    if (s->dtype == 0 || C % 8 != 0 || specs.empty()) return false;
+    struct Slot { int off, h, w; };
+    std::map<std::pair<int, int>, Slot> slot;          // (tensor, 0 as stored / 1 pooled to half size) -> LDS slot
+    int top = 0;                                        // elements
+    auto new_slot = [&](int t, int form, int h, int w) { Slot sl{top, h, w}; top += ((h * w * C + 7) & ~7); slot[{t, form}] = sl; return sl; };
+    std::vector<ChainExt> exts; std::vector<int> ext_t, ext_store_t;
+    std::vector<ChainNode> nodes; std::vector<int> node_out_t;
+    auto pool_pad_of = [&](int n) { int pb, pa; same_pad(n, 3, 2, &pb, &pa); return pb; };
+    auto add_ext = [&](int t, bool pooled, int store_t) {
+      const TensorDesc& td = s->tensors[t];
+      ChainExt x; memset(&x, 0, sizeof x);
+      x.sh = td.H; x.sw = td.W; x.kind = pooled ? SRC_DOWN : SRC_SAME;
+      x.h = pooled ? (td.H + 1) / 2 : td.H; x.w = pooled ? (td.W + 1) / 2 : td.W; x.pool_pad = pool_pad_of(td.H);
+      x.off = new_slot(store_t >= 0 ? store_t : t, store_t >= 0 ? 0 : (pooled ? 1 : 0), x.h, x.w).off;
+      exts.push_back(x); ext_t.push_back(t); ext_store_t.push_back(store_t);
+    };
+    // pools of cell 0
+    for (size_t i = 0; i < pools.size(); i++) {
+      const PoolSpec& ps = pools[i];
+      if (!slot.count({ps.src_t, 0})) {                 // first pool: its input comes from an earlier launch -> pooled while loaded
+        add_ext(ps.src_t, true, ps.out_t);
+      } else {                                          // pool of a map that lives in a slot
+        const Slot in = slot[{ps.src_t, 0}];
+        ChainNode nd; memset(&nd, 0, sizeof nd);
+        nd.pool_only = 1; nd.nsrc = 1; nd.h = (in.h + 1) / 2; nd.w = (in.w + 1) / 2; nd.pool_pad = pool_pad_of(in.h);
+        nd.src[0] = ChainSrc{in.off, SRC_DOWN, in.h, in.w, 1.f};
+        nd.out_off = new_slot(ps.out_t, 0, nd.h, nd.w).off; nd.widx = -1;
+        nodes.push_back(nd); node_out_t.push_back(ps.out_t);
+      }
+    }
+    const size_t es2 = 2, pad = 8;
+    const int wnode_bytes = (int)((size_t)10 * C * 4 + (size_t)C * (C + pad) * es2);
+    std::vector<unsigned char> blob;
+    double bytes = 0, flops = 0, wbytes = 0;
+    int nconv = 0, hw_max = 0;
+    for (const SegSpec& sp : specs) {
+      const int hw = s->levels[sp.level];
+      if (sp.N != C || sp.out_t < 0 || sp.act != ACT_NONE || !sp.pre_act) return false;
+      ChainNode nd; memset(&nd, 0, sizeof nd);
+      nd.nsrc = sp.nsrc; nd.h = hw; nd.w = hw; nd.widx = nconv++;
+      hw_max = std::max(hw_max, hw);
+      for (int j = 0; j < sp.nsrc; j++) {
+        const int t = sp.src[j];
+        const TensorDesc& td = s->tensors[t];
+        bytes += (double)td.H * td.W * C * es();
+        if (slot.count({t, 0})) {                       // a map of this chain (or an input already in a slot), at its own size
+          const Slot sl = slot[{t, 0}];
+          nd.src[j] = ChainSrc{sl.off, sp.kind[j], sl.h, sl.w, sp.fw[j]};
+          if (sp.kind[j] == SRC_DOWN) nd.pool_pad = pool_pad_of(sl.h);
+        } else if (sp.kind[j] == SRC_DOWN) {            // input from a bigger level: pooled while it is loaded
+          if (!slot.count({t, 1})) add_ext(t, true, -1);
+          const Slot sl = slot[{t, 1}];
+          nd.src[j] = ChainSrc{sl.off, SRC_SAME, sl.h, sl.w, sp.fw[j]};
+        } else {
+          add_ext(t, false, -1);
+          const Slot sl = slot[{t, 0}];
+          nd.src[j] = ChainSrc{sl.off, sp.kind[j], sl.h, sl.w, sp.fw[j]};
+        }
+      }
+      nd.out_off = new_slot(sp.out_t, 0, hw, hw).off;
+      nodes.push_back(nd); node_out_t.push_back(sp.out_t);
+      // weights in the kernel's LDS layout
+      const PackTensor* wd = get(sp.key + ".depthwise_conv.conv.weight", {C, 1, 3, 3});
+      const PackTensor* wp = get(sp.key + ".pointwise_conv.conv.weight", {C, C, 1, 1});
+      const PackTensor* bp = get(sp.key + ".pointwise_conv.conv.bias", {C});
+      BnFold bn; if (!fold_bn(pk, sp.bn, C, &bn, err)) ok = false;
+      if (!ok) return true;                             // (the error is reported by the caller through `ok`)
+      const size_t base = blob.size();
+      blob.resize(base + wnode_bytes, 0);
+      float* fdw = reinterpret_cast<float*>(blob.data() + base);
+      for (int c = 0; c < C; c++) for (int t9 = 0; t9 < 9; t9++) fdw[(size_t)t9 * C + c] = wd->data[(size_t)c * 9 + t9];
+      float* fb = fdw + 9 * C;
+      uint16_t* fw = reinterpret_cast<uint16_t*>(fb + C);
+      for (int n = 0; n < C; n++) {
+        fb[n] = bp->data[n] * bn.scale[n] + bn.shift[n];
+        for (int k = 0; k < C; k++) fw[(size_t)n * (C + pad) + k] = f32_to_bf16(wp->data[(size_t)n * C + k] * bn.scale[n]);
+      }
+      bytes += (double)hw * hw * C * es(); flops += 2.0 * hw * hw * C * (9 + C); wbytes += (double)C * C * es() + 10.0 * C * 4;
+    }
+    if (nodes.size() > CH_MAX_NODES || exts.size() > CH_MAX_EXT) return false;
+    ChainArgs ca; memset(&ca, 0, sizeof ca);
+    ca.nnodes = (int)nodes.size(); ca.nconv = nconv; ca.next = (int)exts.size(); ca.C = C; ca.wnode_bytes = wnode_bytes;
+    ca.off_w = ((size_t)top * es2 + 15) & ~(size_t)15;
+    ca.off_halo = ca.off_w + (size_t)nconv * wnode_bytes;
+    ca.off_atile = ca.off_halo + (((size_t)(hw_max + 2) * (hw_max + 2) * (C + pad) * es2 + 15) & ~(size_t)15);
+    ca.lds_bytes = ca.off_atile + (size_t)((hw_max * hw_max + 15) & ~15) * (C + pad) * es2;
+    if (ca.lds_bytes > 158 * 1024) return false;
+    const int op = new_op(OP_CHAIN, name);
+    Op& o = s->ops[op];
+    for (size_t e = 0; e < exts.size(); e++) {
+      ca.ext[e] = exts[e];
+      tref(op, F_CH_EXT_SRC, ext_t[e], false, (int)e);
+      if (ext_store_t[e] >= 0) tref(op, F_CH_EXT_STORE, ext_store_t[e], true, (int)e);
+    }
+    for (size_t n = 0; n < nodes.size(); n++) tref(op, F_CH_NODE_OUT, node_out_t[n], true, (int)n);
+    o.chain = ca; o.cnodes = nodes;
+    const size_t boff = wb.alloc(blob.size());
+    memcpy(wb.host.data() + boff, blob.data(), blob.size());
+    wref(op, F_CH_WBLOB, boff);
+    o.act_bytes_per_image = bytes; o.flops_per_image = flops; o.weight_bytes = wbytes;
+    return true;
+  }
 };
 
 static void fusion_weights(const Pack& pk, const std::string& key, int n, bool attention, float* out, bool* ok, std::string* err) {
@@ -677,6 +788,10 @@ int build_session(Session* s, const Pack& pack, std::string* err) {
   const int Wf = A.fpn_w;
   int feat[5];
   std::vector<Planner::SegSpec> pending; std::vector<std::string> pending_names;   // small-level BiFPN nodes awaiting a chain launch
+  std::vector<Planner::PoolSpec> pending_pools;                                      // cell 0's two max-pools ride in the first chain
+  // HEP_CHAIN: 0 = every node its own launch, 1 = chains inside k_sep.hip (mode 2), 2 (default) = LDS-resident chains
+  // (k_chain.hip) wherever they fit - bf16 / fp8 sessions at BiFPN width 64 - and k_sep.hip chains elsewhere
+  const int chain_mode = getenv("HEP_CHAIN") ? atoi(getenv("HEP_CHAIN")) : 2;
   for (int r = 0; r < A.fpn_cells; r++) {
     const std::string p = "bifpn." + std::to_string(r);
     const std::string tn = "c" + std::to_string(r) + ".";
@@ -706,17 +821,12 @@ int build_session(Session* s, const Pack& pack, std::string* err) {
       }
       in[0] = lat_out[0]; in[1] = lat_out[1]; in[2] = lat_out[2]; in2[1] = lat_out[3]; in2[2] = lat_out[4]; p6pre = lat_out[5];
       if (!P.ok) return HEP_ERR_PACK;
-      int prev = p6pre, ph = L5;
-      for (int l = 3; l < 5; l++) {
+      int prev = p6pre;
+      for (int l = 3; l < 5; l++) {      // p6_in = pool(p6_pre), p7_in = pool(p6_in): launched with the first chain, or on their own
         const int oh = s->levels[l];
         const int t = P.tensor(tn + (l == 3 ? "p6_in" : "p7_in"), oh, oh, Wf);
-        const int op = P.new_op(OP_POOL, tn + (l == 3 ? "p6_pool" : "p7_pool"));
-        Op& o = s->ops[op];
-        int pb, pa; same_pad(ph, 3, 2, &pb, &pa);
-        o.pool.H = ph; o.pool.W = ph; o.pool.C = Wf; o.pool.Ho = oh; o.pool.Wo = oh; o.pool.pad_t = pb; o.pool.pad_l = pb; o.pool.bf16 = s->dtype;
-        P.tref(op, F_POOL_IN, prev, false); P.tref(op, F_POOL_OUT, t, true);
-        o.act_bytes_per_image = ((double)ph * ph + (double)oh * oh) * Wf * P.es();
-        in[l] = t; prev = t; ph = oh;
+        pending_pools.push_back({prev, t, l});
+        in[l] = t; prev = t;
       }
       in2[0] = in[0]; in2[3] = in[3]; in2[4] = in[4];
     } else {
@@ -727,12 +837,26 @@ int build_session(Session* s, const Pack& pack, std::string* err) {
     // per image runs them back to back (k_sep.hip mode 2).  Measured at bs16: a 5-node chain takes
     // 29.8 us against 5 x 7 us as separate launches (a node is ~6 us of dependent global round trips
     // inside the kernel either way; the chain saves the launch boundaries).  HEP_CHAIN=0 disables it.
-    static const bool chain_on = !(getenv("HEP_CHAIN") && atoi(getenv("HEP_CHAIN")) == 0);
+    const bool chain_on = chain_mode != 0;
+    auto emit_pools = [&]() {
+      for (const Planner::PoolSpec& ps : pending_pools) {
+        const TensorDesc& ti = s->tensors[ps.src_t];
+        const int ph = ti.H, oh = s->levels[ps.level];
+        const int op = P.new_op(OP_POOL, s->tensors[ps.out_t].name.substr(0, s->tensors[ps.out_t].name.size() - 3) + "_pool");
+        Op& o = s->ops[op];
+        int pb, pa; same_pad(ph, 3, 2, &pb, &pa);
+        o.pool.H = ph; o.pool.W = ph; o.pool.C = Wf; o.pool.Ho = oh; o.pool.Wo = oh; o.pool.pad_t = pb; o.pool.pad_l = pb; o.pool.bf16 = s->dtype;
+        P.tref(op, F_POOL_IN, ps.src_t, false); P.tref(op, F_POOL_OUT, ps.out_t, true);
+        o.act_bytes_per_image = ((double)ph * ph + (double)oh * oh) * Wf * P.es();
+      }
+      pending_pools.clear();
+    };
     auto flush = [&]() {
-      if (pending.empty()) return;
+      if (pending.empty()) { emit_pools(); return; }
       std::string nm = pending_names.front();
       for (size_t i = 1; i < pending_names.size(); i++) nm += "+" + pending_names[i].substr(pending_names[i].find('.') + 1);
-      P.add_sep(nm, pending, pending.size() > 1);
+      if (chain_mode == 2 && P.add_chain(nm, pending_pools, pending)) pending_pools.clear();
+      else { emit_pools(); if (P.ok) P.add_sep(nm, pending, pending.size() > 1); }
       pending.clear(); pending_names.clear();
     };
     auto node = [&](const char* conv, const char* wkey, int nw, int level, std::vector<std::pair<int, int>> srcs, const std::string& oname) {
@@ -759,7 +883,7 @@ int build_session(Session* s, const Pack& pack, std::string* err) {
   if (!pending.empty()) {
     std::string nm = pending_names.front();
     for (size_t i = 1; i < pending_names.size(); i++) nm += "+" + pending_names[i].substr(pending_names[i].find('.') + 1);
-    P.add_sep(nm, pending, pending.size() > 1);
+    if (!(chain_mode == 2 && P.add_chain(nm, {}, pending))) P.add_sep(nm, pending, pending.size() > 1);
     pending.clear(); pending_names.clear();
   }
   if (!P.ok) return HEP_ERR_PACK;
@@ -858,6 +982,7 @@ int build_session(Session* s, const Pack& pack, std::string* err) {
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { *err = std::string(#x) + ": " + hipGetErrorString(e_); return HEP_ERR_DEVICE; } } while (0)
   HIPCHK(hipSetDevice(s->device));
   if (mbf_prepare() != 0) { *err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for mbf_kernel"; return HEP_ERR_DEVICE; }
+  if (chain_prepare() != 0) { *err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for chain_kernel"; return HEP_ERR_DEVICE; }
   if (tower_prepare() != 0) { *err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for tower_kernel"; return HEP_ERR_DEVICE; }
   if (sep_prepare() != 0) { *err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"; return HEP_ERR_DEVICE; }
   HIPCHK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
@@ -926,6 +1051,10 @@ int build_session(Session* s, const Pack& pack, std::string* err) {
         case F_SEG_WPW: o.segs[r.seg].wpw = ptr; break;
         case F_SEG_BIAS: o.segs[r.seg].bias = (const float*)ptr; break;
         case F_SEG_OUT: o.segs[r.seg].out = ptr; break;
+        case F_CH_EXT_SRC: o.chain.ext[r.seg].src = ptr; break;
+        case F_CH_EXT_STORE: o.chain.ext[r.seg].store = ptr; break;
+        case F_CH_NODE_OUT: o.cnodes[r.seg].out = ptr; break;
+        case F_CH_WBLOB: o.chain.wblob = ptr; break;
       }
     }
     // segment tables to device
@@ -941,6 +1070,10 @@ int build_session(Session* s, const Pack& pack, std::string* err) {
         HIPCHK(hipMemcpy(dt, tile_seg.data(), tile_seg.size() * sizeof(int), hipMemcpyHostToDevice));
         o.sep.tile_seg = dt;
         o.sep.seg0 = o.segs[0];
+      } else if (o.kind == OP_CHAIN) {
+        ChainNode* d; HIPCHK(hipMalloc((void**)&d, o.cnodes.size() * sizeof(ChainNode)));
+        HIPCHK(hipMemcpy(d, o.cnodes.data(), o.cnodes.size() * sizeof(ChainNode), hipMemcpyHostToDevice));
+        o.chain.nodes = d;
       }
   }
 #undef HIPCHK

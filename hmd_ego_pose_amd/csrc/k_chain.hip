@@ -1,0 +1,237 @@
+// k_chain.hip - the small pyramid levels of a BiFPN cell boundary as ONE LDS-resident chain per image (bf16 sessions).
+//
+// Between two visits of the 16x16 / 32x32 levels a BiFPN walks up to five nodes on maps of 8x8, 4x4 and 2x2 pixels
+// (reference efficientdet/model.py:212-264: p5_out -> p6_out -> p7_out -> next cell's p6_up -> p5_up; in cell 0
+// also the two zero-padded max-pools that make p6_in / p7_in, model.py:198-203).  Each node is
+//   swish(sum_i w_i * gather_i)  ->  depthwise 3x3 SAME  ->  pointwise 1x1 (+bias, BN folded)
+// on at most 64 pixels x 64 channels: microseconds of arithmetic.  As a chain inside k_sep.hip (mode 2) every node
+// still paid three to four dependent global round trips (descriptor, gather, weights, store drain): 4.6 us per node,
+// 23 us per chain, 16 workgroups busy - the worst line of the round-1 roofline table (0.0065 of HBM peak).
+//
+// Here one workgroup per image
+//   1. fetches EVERYTHING the chain will need in one burst: the depthwise / pointwise weights and biases of all its
+//      nodes and every external input map (a map that needs the 3x3/2 max-pool is pooled while it is loaded), all into
+//      LDS - one memory round trip for the whole chain;
+//   2. runs the nodes out of LDS: gathers read LDS map slots (external inputs or earlier nodes' outputs), results are
+//      written to their slot and streamed to global memory without waiting (later launches read them from there);
+//   3. three workgroup barriers per node, no global round trip until the kernel ends.
+// Arithmetic, rounding points and operation order are those of sep_kernel (k_sep.hip), so the bf16 stage-parity tests
+// gate it like every other BiFPN node.  Widths other than what fits in LDS (and fp32 sessions) keep the k_sep.hip path.
+#include "hep_dev.h"
+#include "hep_internal.h"
+
+#define CHAIN_THREADS 1024
+#define CHAIN_WAVES 16
+
+namespace {
+
+typedef bf16_t T;
+constexpr int PAD = 8, KSTEP = 32, KLANE = 8;
+
+// 8 channels of a map slot at pixel (y, x) as floats; zero outside the map (SAME padding of the pool / the depthwise halo).
+// The load is unconditional (clamped address) and the zero is a select: conditional loads would each sit in a basic
+// block of their own and serialise into one memory round trip per tap.
+__device__ __forceinline__ u32x4 slot_raw(const T* slot, int h, int w, int C, int y, int x, int c0) {
+  const bool ok = y >= 0 && y < h && x >= 0 && x < w;
+  const int yc = min(max(y, 0), h - 1), xc = min(max(x, 0), w - 1);
+  u32x4 r = *reinterpret_cast<const u32x4*>(slot + (int64_t)(yc * w + xc) * C + c0);
+  if (!ok) r = (u32x4){0, 0, 0, 0};
+  return r;
+}
+__device__ __forceinline__ void unpack8(u32x4 r, float v[8]) {
+#pragma unroll
+  for (int i = 0; i < 4; i++) { v[2 * i] = __uint_as_float(r[i] << 16); v[2 * i + 1] = __uint_as_float(r[i] & 0xffff0000u); }
+}
+__device__ __forceinline__ void slot_load(const T* slot, int h, int w, int C, int y, int x, int c0, float v[8]) {
+  unpack8(slot_raw(slot, h, w, C, y, x, c0), v);
+}
+
+// zero-padded 3x3 stride-2 max-pool of a slot at output pixel (y, x) (utils_extra.py:72-86: the pad value takes part);
+// all nine loads are in flight before the first is consumed
+__device__ __forceinline__ void slot_pool(const T* slot, int h, int w, int C, int pad, int y, int x, int c0, float m[8]) {
+  u32x4 raw[9];
+#pragma unroll
+  for (int q = 0; q < 9; q++) raw[q] = slot_raw(slot, h, w, C, 2 * y - pad + q / 3, 2 * x - pad + q % 3, c0);
+#pragma unroll
+  for (int q = 0; q < 9; q++) {
+    float v[8];
+    unpack8(raw[q], v);
+#pragma unroll
+    for (int c = 0; c < 8; c++) m[c] = q == 0 ? v[c] : fmaxf(m[c], v[c]);
+  }
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(CHAIN_THREADS) void chain_kernel(ChainArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  T* slots = reinterpret_cast<T*>(smem);
+  unsigned char* wreg = smem + a.off_w;
+  T* halo = reinterpret_cast<T*>(smem + a.off_halo);
+  T* atile = reinterpret_cast<T*>(smem + a.off_atile);
+  const int C = a.C, CG = C >> 3, CH = C + PAD;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
+  int cgsh = 0; while ((1 << cgsh) < CG) cgsh++;
+  const int cg = tid & ((1 << cgsh) - 1), prow = tid >> cgsh, pstride = CHAIN_THREADS >> cgsh;
+
+  // ---- 1. one burst: node descriptors, all weights and all external maps -> LDS.  Every load is issued before the
+  //         first LDS store that waits for it, so the whole prologue is about one memory round trip. ----
+  __shared__ ChainNode nd_s[CH_MAX_NODES];
+  {
+    // node descriptors (the node loop reads them from LDS: no dependent global fetch per node; as kernel arguments
+    // indexed at run time they cost a scalar load + wait per field and measured 10 % slower)
+    const int ndw = a.nnodes * (int)(sizeof(ChainNode) / 4);
+    uint32_t dv = 0;
+    if (tid < ndw) dv = reinterpret_cast<const uint32_t*>(a.nodes)[tid];
+    // the chain's weights: one contiguous blob already in the LDS layout (per node [9*C] f32 depthwise | [C] f32 bias |
+    // [C][C+PAD] bf16 pointwise rows)
+    constexpr int WB = 4;
+    const int wvecs = (int)(((size_t)a.nconv * a.wnode_bytes) >> 4);
+    u32x4 wv[WB];
+#pragma unroll
+    for (int j = 0; j < WB; j++) { const int i = tid + j * CHAIN_THREADS; if (i < wvecs) wv[j] = reinterpret_cast<const u32x4*>(a.wblob)[i]; }
+    // external maps that are copied as they are (their own resolution)
+    u32x4 ev[CH_MAX_EXT];
+#pragma unroll
+    for (int e = 0; e < CH_MAX_EXT; e++) {
+      const ChainExt& x = a.ext[e];
+      ev[e] = (u32x4){0, 0, 0, 0};
+      if (e < a.next && x.kind != SRC_DOWN && cg < CG && prow < x.h * x.w)
+        ev[e] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(x.src) + ((int64_t)b * x.sh * x.sw + prow) * C + cg * 8);
+    }
+    if (tid < ndw) reinterpret_cast<uint32_t*>(nd_s)[tid] = dv;
+#pragma unroll
+    for (int j = 0; j < WB; j++) { const int i = tid + j * CHAIN_THREADS; if (i < wvecs) reinterpret_cast<u32x4*>(wreg)[i] = wv[j]; }
+    for (int i = tid + WB * CHAIN_THREADS; i < wvecs; i += CHAIN_THREADS) reinterpret_cast<u32x4*>(wreg)[i] = reinterpret_cast<const u32x4*>(a.wblob)[i];   // (more nodes / wider maps)
+#pragma unroll
+    for (int e = 0; e < CH_MAX_EXT; e++) {
+      const ChainExt& x = a.ext[e];
+      if (e >= a.next || cg >= CG) continue;
+      T* dst = slots + x.off;
+      const T* src = reinterpret_cast<const T*>(x.src) + (int64_t)b * x.sh * x.sw * C;
+      if (x.kind != SRC_DOWN) {
+        if (prow < x.h * x.w) *reinterpret_cast<u32x4*>(dst + (int64_t)prow * C + cg * 8) = ev[e];
+        for (int p = prow + pstride; p < x.h * x.w; p += pstride)
+          *reinterpret_cast<u32x4*>(dst + (int64_t)p * C + cg * 8) = *reinterpret_cast<const u32x4*>(src + (int64_t)p * C + cg * 8);
+      } else {       // pooled while it is loaded (zero-padded 3x3 / 2 max-pool); optionally also a map of its own (p6_in)
+        for (int p = prow; p < x.h * x.w; p += pstride) {
+          float m[8];
+          slot_pool(src, x.sh, x.sw, C, x.pool_pad, p / x.w, p % x.w, cg * 8, m);
+          u32x4 raw;
+#pragma unroll
+          for (int q = 0; q < 4; q++) raw[q] = pack_bf16x2(m[2 * q], m[2 * q + 1]);      // exact: the values are bf16 already
+          *reinterpret_cast<u32x4*>(dst + (int64_t)p * C + cg * 8) = raw;
+          if (x.store) *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(x.store) + ((int64_t)b * x.h * x.w + p) * C + cg * 8) = raw;
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- 2. the nodes, out of LDS (descriptors included); pixel
+  //         indices are split with a reciprocal multiply (a run-time integer division is ~30 instructions on the one
+  //         item a lane has per phase). ----
+#pragma unroll 1      // a real loop: the body runs once per node, unrolled it would be fetched cold every time (measured +20 %)
+  for (int n = 0; n < a.nnodes; n++) {
+    const ChainNode& nd = nd_s[n];
+    const int h = nd.h, w = nd.w, hw = h * w;
+    const uint32_t w_rcp = (uint32_t)(0x100000000ull / (uint32_t)w) + 1, hs_rcp = (uint32_t)(0x100000000ull / (uint32_t)(w + 2)) + 1;
+    T* oslot = slots + nd.out_off;
+    if (nd.pool_only) {          // p7_in = pool(p6_in): a map of its own, no convolution
+      const ChainSrc& s0 = nd.src[0];
+      if (cg < CG)
+        for (int p = prow; p < hw; p += pstride) {
+          float m[8];
+          const int py = (int)__umulhi((uint32_t)p, w_rcp);
+          slot_pool(slots + s0.off, s0.sh, s0.sw, C, nd.pool_pad, py, p - py * w, cg * 8, m);
+          Vec8<true>::store(oslot, (int64_t)p * C + cg * 8, m);
+          Vec8<true>::store(nd.out, ((int64_t)b * hw + p) * C + cg * 8, m);
+        }
+      __syncthreads();
+      continue;
+    }
+    const float* wdw_s = reinterpret_cast<const float*>(wreg + (size_t)nd.widx * a.wnode_bytes);
+    const float* bias_s = wdw_s + 9 * C;
+    const T* wpw_s = reinterpret_cast<const T*>(bias_s + C);
+    const int HS = w + 2;
+    // fused + swished input with its one-pixel zero halo
+    if (cg < CG)
+      for (int pos = prow; pos < (h + 2) * HS; pos += pstride) {
+        const int hy = (int)__umulhi((uint32_t)pos, hs_rcp);
+        const int y = hy - 1, x = pos - hy * HS - 1;
+        float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (y >= 0 && y < h && x >= 0 && x < w) {
+#pragma unroll
+          for (int i = 0; i < HEP_MAX_SRC; i++) {
+            if (i >= nd.nsrc) break;
+            const ChainSrc& s = nd.src[i];
+            float t[8];
+            if (s.kind == SRC_DOWN) slot_pool(slots + s.off, s.sh, s.sw, C, nd.pool_pad, y, x, cg * 8, t);
+            else if (s.kind == SRC_UP) slot_load(slots + s.off, s.sh, s.sw, C, y >> 1, x >> 1, cg * 8, t);
+            else slot_load(slots + s.off, s.sh, s.sw, C, y, x, cg * 8, t);
+#pragma unroll
+            for (int c = 0; c < 8; c++) v[c] = fmaf(s.fw, t[c], v[c]);
+          }
+#pragma unroll
+          for (int c = 0; c < 8; c++) v[c] = swish_t<true>(v[c]);
+        }
+        Vec8<true>::store(halo, (int64_t)pos * CH + cg * 8, v);
+      }
+    __syncthreads();
+    // depthwise 3x3 -> MFMA operand tile [pixels][C]; rows beyond the map are zeroed (their products are discarded)
+    if (cg < CG)
+      for (int p = prow; p < ((hw + 15) & ~15); p += pstride) {
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (p < hw) {
+          const int py = (int)__umulhi((uint32_t)p, w_rcp), px = p - py * w;
+#pragma unroll
+          for (int q = 0; q < 9; q++) {
+            float hv[8];
+            Vec8<true>::load(halo, (int64_t)((py + q / 3) * HS + px + q % 3) * CH + cg * 8, hv);
+            const f32x4* wp = reinterpret_cast<const f32x4*>(wdw_s + q * C + cg * 8);
+            const f32x4 w0 = wp[0], w1 = wp[1];
+#pragma unroll
+            for (int c = 0; c < 4; c++) { acc[c] = fmaf(hv[c], w0[c], acc[c]); acc[4 + c] = fmaf(hv[4 + c], w1[c], acc[4 + c]); }
+          }
+        }
+        Vec8<true>::store(atile, (int64_t)p * CH + cg * 8, acc);
+      }
+    __syncthreads();
+    // pointwise: D[n, pixel] = W[n, :] . tile[pixel, :]; (m-tile, n-tile) pairs dealt to the waves; lane ends with 4
+    // consecutive channels of one pixel -> its slot in LDS
+    const int mt_n = (hw + 15) >> 4, nt_n = C >> 4, ksteps = (C + KSTEP - 1) / KSTEP;
+    for (int pair = wave; pair < mt_n * nt_n; pair += CHAIN_WAVES) {
+      const int mt = (int)__umulhi((uint32_t)pair, (uint32_t)(0x100000000ull / (uint32_t)nt_n) + 1), nt = pair - mt * nt_n;
+      const int m = mt * 16 + r;
+      const T* wrow = wpw_s + (int64_t)(nt * 16 + r) * CH + KLANE * g;
+      const T* arow = atile + (int64_t)m * CH + KLANE * g;
+      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int ks = 0; ks < ksteps; ks++) {
+        u32x4 wf = {}, xa = {};
+        if (ks * KSTEP + KLANE * g < C) { wf = *reinterpret_cast<const u32x4*>(wrow + ks * KSTEP); xa = *reinterpret_cast<const u32x4*>(arow + ks * KSTEP); }
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf), __builtin_bit_cast(bf16x8, xa), acc, 0, 0, 0);
+      }
+      const int nn = nt * 16 + 4 * g;
+      if (m < hw) {
+        const f32x4 bias = *reinterpret_cast<const f32x4*>(bias_s + nn);
+        float v[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) v[q] = acc[q] + bias[q];
+        Vec8<true>::store4(oslot, (int64_t)m * C + nn, v);
+      }
+    }
+    __syncthreads();
+    // the finished map leaves as full 16-byte vectors; nobody in this launch reads it from global memory
+    if (cg < CG)
+      for (int p = prow; p < hw; p += pstride)
+        *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(nd.out) + ((int64_t)b * hw + p) * C + cg * 8) = *reinterpret_cast<const u32x4*>(oslot + (int64_t)p * C + cg * 8);
+  }
+}
+
+int chain_prepare(void) {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024) == hipSuccess ? 0 : -1;
+}
+
+void launch_chain(const ChainArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(chain_kernel, dim3(a.B), dim3(CHAIN_THREADS), a.lds_bytes, s, a);
+}

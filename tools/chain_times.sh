@@ -1,0 +1,14 @@
+#!/bin/bash
+# per-launch durations of one device function over the last forwards of a one-batch-in-flight bench run
+# usage (GPU box): tools/chain_times.sh <kernel substring> [count]
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/tr
+rocprofv3 --kernel-trace --output-format csv -d /tmp/tr -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-comm --inflight 1 > /dev/null 2>&1
+python3 - "$1" "${2:-8}" <<'PY'
+import csv, glob, sys
+f = glob.glob("/tmp/tr/**/*kernel_trace.csv", recursive=True)[0]
+rows = [r for r in csv.DictReader(open(f)) if sys.argv[1] in r["Kernel_Name"]]
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows][-int(sys.argv[2]):]
+print(sys.argv[1], "launches (us):", [round(x, 1) for x in d])
+PY
