@@ -85,6 +85,44 @@ def cpu_baseline(phi, size, budget_s=15.0):
                       f"forward + anchors + box/translation decode, {el:.1f} s, best of 8..128 torch threads on {os.cpu_count()} host CPUs"}
 
 
+def add_vs_ref(phi, size, precisions=("fp32", "bf16", "fp8")):
+    """The accuracy half of the metric ("ADD(-S) vs ref"), part of the CPU-baseline leg because it needs the oracle: for
+    a few seeded frames the oracle (the reference's arithmetic, fp32) and the HIP path predict a pose at the same anchor
+    (the oracle's best-scoring one); ADD / ADD-S between the two poses over a 1000-point cloud of the drill's size
+    (hep_pose_errors), in the translation unit (mm).  No dataset or checkpoint ships with the reference, so this is the
+    distance to the reference's OUTPUT on synthetic weights, not an accuracy against ground truth; random-init networks
+    amplify rounding, so the bf16 / fp8 figures are upper bounds for trained weights."""
+    import math
+    import numpy as np
+    import torch
+    from hmd_ego_pose_amd.evaluate import pose_errors
+    from hmd_ego_pose_amd.model import Session
+    from hmd_ego_pose_amd.weights import seeded_state_dict
+    from oracle import decode_ref as D
+    from oracle import efficientpose_ref as R
+    sd = seeded_state_dict(phi, 0)
+    nf = 4
+    rng = np.random.Generator(np.random.PCG64(99))
+    x = torch.from_numpy(rng.standard_normal((nf, 3, size, size)).astype(np.float32))
+    cam = np.array([[480, 480, 128, 128, 1000, 1.0]] * nf, np.float32)
+    pts = (rng.standard_normal((1000, 3)) * np.array([40.0, 25.0, 60.0])).astype(np.float32)
+    _, reg, cls, rot, trn, hand = R.forward(sd, x, phi)
+    _, t_anchors = D.anchors_for_size(size)
+    t_ref = D.decode_translation(t_anchors, trn.numpy(), cam)
+    idx = cls[:, :, 0].argmax(dim=1).numpy()
+    pick = lambda a: np.stack([a[i, idx[i]] for i in range(nf)])
+    out = {}
+    for prec in precisions:
+        s_ = Session(sd, phi, size, nf, prec)
+        _, g_reg, _g_cls, g_rot, g_trn, _g_hand = s_.forward(x.cuda(), want_features=False)
+        _, g_t = s_.decode(g_reg, g_trn, torch.from_numpy(cam).cuda())
+        add, add_s = pose_errors(pts, pick(rot.numpy()) * math.pi, pick(t_ref), pick(g_rot.cpu().numpy()) * math.pi, pick(g_t.cpu().numpy()))
+        out[prec] = {"add_mm": round(float(add.mean()), 5), "add_s_mm": round(float(add_s.mean()), 5)}
+        s_.close()
+    out["sample"] = f"{nf} seeded frames, pose at the oracle's best-scoring anchor, 1000-point cloud (sigma 40/25/60 mm), translations ~ N(0, 1) * 1000 mm"
+    return out
+
+
 def pmc_traffic(symbol):
     """HBM bytes per launch of `symbol` from the newest committed PMC pass (profiles/r*/*_pmc_per_kernel.json:
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, KB per launch).  gfx950 correction from
@@ -292,6 +330,7 @@ def main():
                 for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:5]]
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(phi, S)
+                out["add_vs_ref"] = add_vs_ref(phi, S)
         print(json.dumps(out), flush=True)
     for s_ in sess:
         s_.close()

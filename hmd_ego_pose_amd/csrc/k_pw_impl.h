@@ -83,6 +83,35 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
     kbeg = min(K, wave * per * F::KSTEP); kend = min(K, (wave + 1) * per * F::KSTEP);
   }
 
+  int mrow[MT]; bool mok[MT];
+#pragma unroll
+  for (int i = 0; i < MT; i++) { mrow[i] = m0 + i * 16 + r; mok[i] = mrow[i] < M; }
+  auto load = [&](Step<PREC, MT, NT>& st, int kk) {
+    const int k = kk + F::KLANE * g;
+    const bool kok = k < kend;
+#pragma unroll
+    for (int i = 0; i < MT; i++) {
+      raw_t v = {};
+      if (kok && mok[i]) v = *reinterpret_cast<const raw_t*>(A + (int64_t)mrow[i] * K + k);
+      st.a[i] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < NT; j++) {
+      if constexpr (F8) {
+        u32x2 v = {};
+        if (kok && ntile0 + j < a.tilesN) v = *reinterpret_cast<const u32x2*>(W8 + (int64_t)((ntile0 + j) * 16 + r) * K + k);
+        st.w[j] = v;
+      } else {
+        raw_t v = {};
+        if (kok && ntile0 + j < a.tilesN) v = *reinterpret_cast<const raw_t*>(W + (int64_t)((ntile0 + j) * 16 + r) * K + k);
+        st.w[j] = v;
+      }
+    }
+  };
+  // the first k-step's fragments do not depend on the squeeze-excite scale: they are in flight during the prologue
+  Step<PREC, MT, NT> cur, nxt;
+  if (kbeg < kend) load(cur, kbeg);
+
   // ---- squeeze-excite prologue: scale_s[image - img0][k] for the images this workgroup's rows belong to ----
   // A chain of dependent round trips if written naively (hpart rows -> hidden -> weight rows -> scale), and it
   // sits in front of every project GEMM, so: the first batch of expand-FC weight rows (independent of the hidden
@@ -182,40 +211,15 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
     }
   }
 
-  int mrow[MT]; bool mok[MT]; int mimg[MT];
+  int mimg[MT];
 #pragma unroll
-  for (int i = 0; i < MT; i++) {
-    mrow[i] = m0 + i * 16 + r; mok[i] = mrow[i] < M;
-    mimg[i] = (SE && mok[i]) ? mrow[i] / a.HW - img0 : 0;
-  }
+  for (int i = 0; i < MT; i++) mimg[i] = (SE && mok[i]) ? mrow[i] / a.HW - img0 : 0;
   f32x4 acc[MT][NT];
 #pragma unroll
   for (int i = 0; i < MT; i++)
 #pragma unroll
     for (int j = 0; j < NT; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  auto load = [&](Step<PREC, MT, NT>& st, int kk) {
-    const int k = kk + F::KLANE * g;
-    const bool kok = k < kend;
-#pragma unroll
-    for (int i = 0; i < MT; i++) {
-      raw_t v = {};
-      if (kok && mok[i]) v = *reinterpret_cast<const raw_t*>(A + (int64_t)mrow[i] * K + k);
-      st.a[i] = v;
-    }
-#pragma unroll
-    for (int j = 0; j < NT; j++) {
-      if constexpr (F8) {
-        u32x2 v = {};
-        if (kok && ntile0 + j < a.tilesN) v = *reinterpret_cast<const u32x2*>(W8 + (int64_t)((ntile0 + j) * 16 + r) * K + k);
-        st.w[j] = v;
-      } else {
-        raw_t v = {};
-        if (kok && ntile0 + j < a.tilesN) v = *reinterpret_cast<const raw_t*>(W + (int64_t)((ntile0 + j) * 16 + r) * K + k);
-        st.w[j] = v;
-      }
-    }
-  };
   auto compute = [&](Step<PREC, MT, NT>& st, int kk) {
     // squeeze-excite scales of this lane's k run (LDS; rows outside M or k >= kend hold zeros in A anyway)
     const int ks = min(kk + F::KLANE * g, K - F::KLANE);
@@ -272,8 +276,6 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
   };
 
   if (kbeg < kend) {
-    Step<PREC, MT, NT> cur, nxt;
-    load(cur, kbeg);
     int kk = kbeg;
     for (; kk + F::KSTEP < kend; kk += F::KSTEP) {
       load(nxt, kk + F::KSTEP);
