@@ -104,8 +104,14 @@ template <> struct Vec8<false> {
 // XCD-aware block remap (guide T1): hardware deals consecutive block ids round-robin over the
 // 8 XCDs; give each XCD a contiguous range of logical ids so neighbours share an L2.  Bijective
 // for any grid size.
+// two-dimensional grids: the hardware deals the LINEAR block id (x + y * gx) round-robin, so the remap works on that
+__device__ __forceinline__ void xcd_remap2(int bx, int by, int gx, int gy, int* x, int* y);
 __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
   int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
   int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   return base + (orig >> 3);
+}
+__device__ __forceinline__ void xcd_remap2(int bx, int by, int gx, int gy, int* x, int* y) {
+  const int logical = xcd_remap(bx + by * gx, gx * gy);
+  *y = logical / gx; *x = logical - *y * gx;
 }

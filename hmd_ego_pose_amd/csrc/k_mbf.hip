@@ -64,8 +64,11 @@ __global__ __launch_bounds__(TS == 16 ? 1024 : 512) void mbf_kernel(MbfArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, g = lane >> 4;
   const int chunks = (a.Cexp + a.CC - 1) / a.CC;
-  const int tile = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
-  const int b = blockIdx.y;
+  // XCD-aware order: the workgroups of one tile (its channel chunks) all stage the same input pixels; as consecutive
+  // LOGICAL blocks they share an XCD and its L2 instead of fetching the tile into up to eight of them
+  int bxl, b;
+  xcd_remap2(blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, &bxl, &b);
+  const int tile = bxl / chunks, chunk = bxl % chunks;
   const int tiles_x = (a.Wo + TS - 1) / TS;
   const int oy0 = (tile / tiles_x) * TS, ox0 = (tile % tiles_x) * TS;
   const int iy0 = oy0 * S - a.pad_t, ix0 = ox0 * S - a.pad_l;     // input coords of tile pixel (0,0)
@@ -347,7 +350,7 @@ __global__ __launch_bounds__(TS == 16 ? 1024 : 512) void mbf_kernel(MbfArgs a) {
       }
     }
     const int tiles = tiles_x * ((a.Ho + TS - 1) / TS);
-    float* hrow = a.hpart + ((int64_t)b * tiles * chunks + blockIdx.x) * a.sqp;
+    float* hrow = a.hpart + ((int64_t)b * tiles * chunks + bxl) * a.sqp;
     for (int j = threadIdx.x >> 3; j < ((a.sq + 63) & ~63); j += MBF_THREADS / 8) {
       float dot = 0.f;
       if (j < a.sq && ch < cc) {
@@ -362,7 +365,7 @@ __global__ __launch_bounds__(TS == 16 ? 1024 : 512) void mbf_kernel(MbfArgs a) {
 #ifdef HEP_MBF_TRACE
   MSTAMP(6);
   if (g_mbf_trace && a.trace && lane == 0) {
-    unsigned long long* o = g_mbf_trace + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * MBF_WAVES + wave) * 8;
+    unsigned long long* o = g_mbf_trace + ((size_t)(b * gridDim.x + bxl) * MBF_WAVES + wave) * 8;
     for (int i = 0; i < 7; i++) o[i] = stamps[i];
     o[7] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
   }

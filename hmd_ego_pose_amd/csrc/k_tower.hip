@@ -128,7 +128,11 @@ __global__ __launch_bounds__(256, BF16 ? 4 : 2) void tower_kernel(const SepSeg* 
   float* bias_s = wdw_s + 9 * CW;
   T* w_s = reinterpret_cast<T*>(smem + Cfg::OFF_W);
 
-  const int si = __builtin_amdgcn_readfirstlane(tile_seg[blockIdx.x]);
+  // XCD-aware order: consecutive LOGICAL blocks are neighbouring 8x8 tiles of one map, whose 6x6 patch halos overlap:
+  // on one XCD the overlap is an L2 hit instead of a second fetch (PMC round 1: 1.37x the algorithmic reads)
+  int bxl, byl;
+  xcd_remap2(blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, &bxl, &byl);
+  const int si = __builtin_amdgcn_readfirstlane(tile_seg[bxl]);
   const SepSeg* __restrict__ sg = segs + si;           // uniform + read-only: descriptor fields arrive as scalar loads
   const int h = sg->h, w = sg->w, tiles_x = sg->tiles_x, tilesN = sg->tilesN;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
@@ -166,8 +170,8 @@ __global__ __launch_bounds__(256, BF16 ? 4 : 2) void tower_kernel(const SepSeg* 
 
   // one workgroup = one 8x8 tile position of `ipb` consecutive images: the staged weights are shared
   // and the taps of image i+1 are in flight while image i goes through the MFMAs
-  const int t = blockIdx.x - sg->tile_begin;
-  const int b0 = blockIdx.y * ipb, nimg = min(ipb, B - b0);
+  const int t = bxl - sg->tile_begin;
+  const int b0 = byl * ipb, nimg = min(ipb, B - b0);
   const int ty = t / tiles_x, tx = t - ty * tiles_x;
   const int y0 = ty * 8 + (wave >> 1) * 4, x0 = tx * 8 + (wave & 1) * 4;   // this wave's 4x4 patch
   const int y = y0 + (r >> 2), x = x0 + (r & 3);                            // this lane's pixel (MFMA row/col r)
@@ -365,7 +369,7 @@ __global__ __launch_bounds__(256, BF16 ? 4 : 2) void tower_kernel(const SepSeg* 
   TSTAMP_NOWAIT(5);                    // MFMA + stores issued
   TSTAMP(6);                           // stores acknowledged
   if (g_tower_trace && lane == 0) {
-    unsigned long long* o = g_tower_trace + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 8;
+    unsigned long long* o = g_tower_trace + ((size_t)(byl * gridDim.x + bxl) * 4 + wave) * 8;
     for (int i = 0; i < 7; i++) o[i] = stamps[i];
     o[7] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
   }
