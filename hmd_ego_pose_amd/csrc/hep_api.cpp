@@ -513,6 +513,24 @@ int hep_pose_errors(int device, const float* points, int num_points, const float
   return 0;
 }
 
+// ---- training side ----
+int hep_anchor_targets_device(const float* anchors, int num_anchors, const double* gt_boxes, const int32_t* gt_labels,
+                              const float* gt_transform, const float* gt_coords, const int32_t* num_gt, const int32_t* image_hw,
+                              int batch, int kmax, int num_classes, int num_transform, double negative_overlap, double positive_overlap,
+                              float* labels, float* regression, float* transformation, float* coords, void* stream) {
+  if (!anchors || !gt_boxes || !gt_labels || !gt_transform || !num_gt || !image_hw || !labels || !regression || !transformation)
+    return fail(HEP_ERR_INVALID, "bad argument");
+  if (num_anchors < 1 || batch < 1 || num_classes < 1 || num_transform < 0) return fail(HEP_ERR_INVALID, "bad size");
+  if (kmax < 1 || kmax > AT_MAX_GT) return fail(HEP_ERR_UNSUPPORTED, "kmax must be in 1..64 ground-truth boxes per image");
+  AnchorTargetArgs a; a.anchors = anchors; a.N = num_anchors; a.gt_boxes = gt_boxes; a.gt_labels = gt_labels; a.gt_transform = gt_transform;
+  a.gt_coords = gt_coords; a.num_gt = num_gt; a.image_hw = image_hw; a.B = batch; a.kmax = kmax; a.num_classes = num_classes; a.rt = num_transform;
+  a.negative_overlap = negative_overlap; a.positive_overlap = positive_overlap;
+  a.labels = labels; a.regression = regression; a.transformation = transformation; a.coords = coords;
+  launch_anchor_targets(a, (hipStream_t)stream);
+  HIPRET(hipGetLastError());
+  return 0;
+}
+
 // ---- introspection ----
 int hep_debug_tensor_count(const hep_handle* h) { return h ? (int)h->s.tensors.size() : 0; }
 int hep_debug_tensor_info(const hep_handle* h, int i, const char** name, int64_t dims[4]) {

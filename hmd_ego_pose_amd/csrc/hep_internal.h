@@ -157,6 +157,18 @@ struct PoseErrArgs {
 };
 void launch_pose_errors(const PoseErrArgs&, hipStream_t);
 
+// ---- training side: anchor-target assignment (generators/utils/anchors.py:69-221) ----
+#define AT_MAX_GT 64
+struct AnchorTargetArgs {
+  const float* anchors; int N;                                     // [N,4]
+  const double* gt_boxes; const int32_t* gt_labels;                // [B][kmax][4] x1,y1,x2,y2 ; [B][kmax]
+  const float* gt_transform; const float* gt_coords;               // [B][kmax][rt] ; [B][kmax][63] (nullable)
+  const int32_t* num_gt; const int32_t* image_hw;                  // [B] ; [B][2] (height, width)
+  int B, kmax, num_classes, rt; double negative_overlap, positive_overlap;
+  float* labels; float* regression; float* transformation; float* coords;   // [B][N][C+1], [B][N][5], [B][N][rt+1], [B][N][64] (nullable)
+};
+void launch_anchor_targets(const AnchorTargetArgs&, hipStream_t);
+
 void launch_stem(const StemArgs&, hipStream_t);
 void launch_pw(const PwArgs&, hipStream_t);
 int pw_se_variant(const PwArgs&);   // 0 none, 1 shallow, 2 deep (template parameter of pw_gemm_kernel)

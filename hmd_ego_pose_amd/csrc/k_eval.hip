@@ -79,3 +79,101 @@ __global__ __launch_bounds__(EVAL_THREADS) void pose_error_kernel(PoseErrArgs a)
 void launch_pose_errors(const PoseErrArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(pose_error_kernel, dim3(a.D), dim3(EVAL_THREADS), 0, s, a);
 }
+
+// ------------------------------------------------------------------------------------------------
+// Training-side anchor-target assignment: the reference computes it per batch on the host with
+// numpy + a Cython IoU matrix (generators/utils/anchors.py:69-221, compute_overlap.pyx:33-73, bbox_transform
+// anchors.py:422-458).  Here one workgroup per image:
+//   pass 1  for every ground-truth box k the anchor of greatest IoU (lowest index on ties; anchor 0 for a box that
+//           overlaps nothing - numpy's argmax of a zero column): forced positive
+//   pass 2  per anchor: IoU with every box in float64 with the "+1" convention, the box of greatest overlap (lowest
+//           index on ties), state = 1 if overlap >= positive or forced, -1 if overlap > negative (and not positive) or
+//           the anchor's centre lies outside the image, else 0; one-hot label, (ty, tx, th, tw) regression targets
+//           (anchor side in float32, box side in float64 like the numpy expressions), transformation / hand targets of
+//           the assigned box
+// Index decisions are exact (same float64 arithmetic, same tie rules); the regression targets differ from numpy's by
+// the last ulps of log().
+// ------------------------------------------------------------------------------------------------
+#define AT_THREADS 1024
+__device__ __forceinline__ double iou_plus1(const float* an, const double* q) {
+#pragma clang fp contract(off)
+  const double a0 = an[0], a1 = an[1], a2 = an[2], a3 = an[3];
+  const double iw = fmin(a2, q[2]) - fmax(a0, q[0]) + 1.0;
+  if (!(iw > 0)) return 0.0;
+  const double ih = fmin(a3, q[3]) - fmax(a1, q[1]) + 1.0;
+  if (!(ih > 0)) return 0.0;
+  const double box_area = (q[2] - q[0] + 1.0) * (q[3] - q[1] + 1.0);
+  const double ua = (a2 - a0 + 1.0) * (a3 - a1 + 1.0) + box_area - iw * ih;
+  return iw * ih / ua;
+}
+
+__global__ __launch_bounds__(AT_THREADS) void anchor_targets_kernel(AnchorTargetArgs a) {
+#pragma clang fp contract(off)
+  __shared__ double red_v[AT_THREADS];
+  __shared__ int red_i[AT_THREADS];
+  __shared__ int forced[AT_MAX_GT];
+  const int b = blockIdx.x, t = threadIdx.x;
+  const int K = min(a.num_gt[b], a.kmax);
+  const double* gt = a.gt_boxes + (int64_t)b * a.kmax * 4;
+  for (int k = 0; k < K; k++) {
+    double best = -1.0; int bi = 0x7fffffff;
+    for (int i = t; i < a.N; i += AT_THREADS) {
+      const double v = iou_plus1(a.anchors + 4 * i, gt + 4 * k);
+      if (v > best) { best = v; bi = i; }               // ascending i: the first maximum is kept
+    }
+    red_v[t] = best; red_i[t] = bi;
+    __syncthreads();
+    for (int o = AT_THREADS / 2; o > 0; o >>= 1) {
+      if (t < o) {
+        const double v2 = red_v[t + o]; const int i2 = red_i[t + o];
+        if (v2 > red_v[t] || (v2 == red_v[t] && i2 < red_i[t])) { red_v[t] = v2; red_i[t] = i2; }
+      }
+      __syncthreads();
+    }
+    if (t == 0) forced[k] = red_i[0];
+    __syncthreads();
+  }
+  const int NC = a.num_classes, RT = a.rt;
+  const float img_h = (float)a.image_hw[2 * b], img_w = (float)a.image_hw[2 * b + 1];
+  for (int i = t; i < a.N; i += AT_THREADS) {
+    const float* an = a.anchors + 4 * i;
+    float* lab = a.labels + ((int64_t)b * a.N + i) * (NC + 1);
+    float* reg = a.regression + ((int64_t)b * a.N + i) * 5;
+    float* tra = a.transformation + ((int64_t)b * a.N + i) * (RT + 1);
+    float* crd = a.coords ? a.coords + ((int64_t)b * a.N + i) * 64 : nullptr;
+    float state = 0.f;
+    int arg = 0;
+    for (int c = 0; c < NC; c++) lab[c] = 0.f;
+    if (K > 0) {
+      double mx = -1.0;
+      for (int k = 0; k < K; k++) { const double v = iou_plus1(an, gt + 4 * k); if (v > mx) { mx = v; arg = k; } }
+      bool pos = mx >= a.positive_overlap;
+      for (int k = 0; k < K; k++) pos = pos || forced[k] == i;
+      if (pos) state = 1.f; else if (mx > a.negative_overlap) state = -1.f;
+      if (pos) { const int l = a.gt_labels[(int64_t)b * a.kmax + arg]; if (l >= 0 && l < NC) lab[l] = 1.f; }
+      // bbox_transform: anchor side float32, box side float64
+      float wa = an[2] - an[0], ha = an[3] - an[1];
+      const float cxa = an[0] + wa / 2.f, cya = an[1] + ha / 2.f;
+      const double* q = gt + 4 * arg;
+      double w = q[2] - q[0], h = q[3] - q[1];
+      const double cx = q[0] + w / 2.0, cy = q[1] + h / 2.0;
+      ha += 1e-7f; wa += 1e-7f; h += 1e-7; w += 1e-7;
+      reg[0] = (float)((cy - (double)cya) / (double)ha); reg[1] = (float)((cx - (double)cxa) / (double)wa);
+      reg[2] = (float)log(h / (double)ha); reg[3] = (float)log(w / (double)wa);
+      for (int j = 0; j < RT; j++) tra[j] = a.gt_transform[((int64_t)b * a.kmax + arg) * RT + j];
+      if (crd) for (int j = 0; j < 63; j++) crd[j] = a.gt_coords ? a.gt_coords[((int64_t)b * a.kmax + arg) * 63 + j] : 0.f;
+    } else {
+      for (int j = 0; j < 4; j++) reg[j] = 0.f;
+      for (int j = 0; j < RT; j++) tra[j] = 0.f;
+      if (crd) for (int j = 0; j < 63; j++) crd[j] = 0.f;
+    }
+    const float cx_a = (an[0] + an[2]) / 2.f, cy_a = (an[1] + an[3]) / 2.f;
+    if (cx_a >= img_w || cy_a >= img_h) state = -1.f;
+    lab[NC] = state; reg[4] = state; tra[RT] = state;
+    if (crd) crd[63] = state;
+  }
+}
+
+void launch_anchor_targets(const AnchorTargetArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(anchor_targets_kernel, dim3(a.B), dim3(AT_THREADS), 0, s, a);
+}

@@ -21,6 +21,7 @@
  *                                 (C# twins Program.cs:225-470)
  *   hep_filter / _device       <- FilterDetections / filter_detections, pytorch-sandbox/hmdegopose/layers.py:264-482
  *                                 (C# twin Program.cs:472-627)
+ *   hep_anchor_targets_device  <- anchor_targets_bbox, pytorch-sandbox/generators/utils/anchors.py:69-221 (training side)
  *   hep_pose_errors / _device  <- check_6d_pose_add / check_6d_pose_add_s, pytorch-sandbox/eval/common.py:682-746 with
  *                                 c_min_distances, pytorch-sandbox/generators/utils/calc_min_distances.h:24-35 (the
  *                                 metric arithmetic of evaluate.py's loop, eval/common.py:866-1121)
@@ -150,6 +151,19 @@ int hep_pose_errors(int device, const float* points, int num_points, const float
 int hep_pose_errors_device(const float* points, int num_points, const float* rvec_gt, const float* t_gt,
                            const float* rvec_pred, const float* t_pred, int num_pairs, int max_points, double* add,
                            double* add_s, void* stream);
+
+/* Training side: anchor_targets_bbox, pytorch-sandbox/generators/utils/anchors.py:69-221 with the IoU
+ * matrix of generators/utils/compute_overlap.pyx:33-73 and bbox_transform anchors.py:422-458, on device memory: per
+ * image the ground-truth boxes [batch][kmax][4] (float64 x1,y1,x2,y2; the first num_gt[b] are valid), their labels,
+ * transformation targets [batch][kmax][num_transform] and (optionally) hand coordinates [batch][kmax][63]; image_hw
+ * [batch][2] = (height, width) of the unpadded image.  Outputs as the reference builds them (float32): labels
+ * [batch][N][num_classes+1], regression [batch][N][5] = (ty,tx,th,tw,state), transformation [batch][N][num_transform+1],
+ * coords [batch][N][64] (may be NULL); the last column is the anchor state: -1 ignore, 0 background, 1 object.
+ * The losses (hmdegopose/loss.py:54-428) are torch code in the reference and stay with torch autograd. */
+int hep_anchor_targets_device(const float* anchors, int num_anchors, const double* gt_boxes, const int32_t* gt_labels,
+                              const float* gt_transform, const float* gt_coords, const int32_t* num_gt, const int32_t* image_hw,
+                              int batch, int kmax, int num_classes, int num_transform, double negative_overlap, double positive_overlap,
+                              float* labels, float* regression, float* transformation, float* coords, void* stream);
 
 /* preprocess_image (reference generators/colibri_common.py:622-656): device uint8 RGB [batch, height, width, 3] ->
  * device float32 [batch, size, size, 3]: resize by scale = size / max(height, width) (8-bit bilinear, OpenCV

@@ -178,3 +178,45 @@ def test_preprocess_matches_the_imported_reference_and_resize_convention():
     tall = np.zeros((300, 200, 3), np.uint8)
     out, scale = D.preprocess_image(tall, 256)
     assert abs(scale - 256 / 300) < 1e-15 and np.all(out[:, int(200 * scale):] == 0) and np.all(out[:, :int(200 * scale)] != 0)
+
+
+def test_anchor_targets_match_the_imported_reference():
+    """oracle/train_ref.py against the REAL reference's anchor_targets_bbox / compute_gt_annotations / bbox_transform
+    (generators/utils/anchors.py with its own Cython IoU extension compiled out of tree by
+    tests/golden/make_golden_targets.py): sha256-identical arrays for one box, no box, a partly outside image, a box equal
+    to an anchor + a box that overlaps nothing; the core assignment also for several boxes (where the reference's own
+    batch assembly raises on its coords_3d reshape)."""
+    import hashlib
+    import importlib.util
+    import os
+    from oracle import train_ref as T
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("mgt", os.path.join(here, "golden", "make_golden_targets.py"))
+    mgt = importlib.util.module_from_spec(spec); spec.loader.exec_module(mgt)
+    fx = np.load(os.path.join(here, "golden", "anchor_targets.npz"))
+    anchors, _ = D.anchors_for_size(256)
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest()
+    seen = 0
+    for name, shape, boxes, labels, tt, coords in mgt.cases(anchors):
+        K = boxes.shape[0]
+        if K:
+            pos, ign, arg = T.compute_gt_annotations(anchors, boxes)
+            assert sha(pos.astype(np.uint8)) == fx[f"{name}_positive_sha256"].tobytes(), name
+            assert sha(ign.astype(np.uint8)) == fx[f"{name}_ignore_sha256"].tobytes(), name
+            assert sha(arg.astype(np.int64)) == fx[f"{name}_argmax_sha256"].tobytes(), name
+            assert sha(T.bbox_transform(anchors, boxes[arg, :]).astype(np.float64)) == fx[f"{name}_bbox_transform_sha256"].tobytes(), name
+            assert [int(pos.sum()), int(ign.sum())] == fx[f"{name}_counts"].tolist()
+        if f"{name}_labels_sha256" in fx:
+            seen += 1
+            c = np.repeat(coords[:1], max(K, 1), 0) if K else np.zeros((0, 63))
+            lab, reg, tra, crd = T.anchor_targets(anchors, [shape], [boxes], [labels], [tt], [c], 1)
+            for key, arr in (("labels", lab), ("regression", reg), ("transformation", tra), ("coords", crd)):
+                assert arr.dtype == np.float32 and sha(arr) == fx[f"{name}_{key}_sha256"].tobytes(), (name, key)
+            st = reg[..., -1]
+            assert [(st == -1).sum(), (st == 0).sum(), (st == 1).sum()] == fx[f"{name}_state_hist"].tolist()
+    assert seen >= 3          # one, none, exact_anchor (the reference raises on its coords_3d reshape for the others)
+    # known answers: a box equal to an anchor makes that anchor positive with zero regression targets; a box nothing
+    # overlaps forces anchor 0 positive
+    boxes = np.stack([anchors[4000].astype(np.float64), np.array([1000., 1000., 1010., 1010.])])
+    pos, ign, arg = T.compute_gt_annotations(anchors, boxes)
+    assert pos[4000] and arg[4000] == 0 and pos[0] and np.allclose(T.bbox_transform(anchors, boxes[arg, :])[4000], 0, atol=1e-6)

@@ -618,3 +618,34 @@ def test_evaluator_on_a_synthetic_linemod_folder(api, tmp_path):
                 break
     assert res["num_matched"] == matched
     assert res["ADD"] == n_ok_add / 5 and res["ADD-S"] == n_ok_adds / 5 and 0.0 <= res["AP"] <= 1.0
+
+
+def test_anchor_targets_match_oracle(api):
+    """Training-side anchor-target assignment on the GPU (hep_anchor_targets_device) against oracle/train_ref.py (pinned
+    bit for bit to the imported reference, tests/test_decode_oracle_cpu.py): anchor states, one-hot labels, transformation
+    and hand targets bit-exact (same float64 IoU arithmetic and tie rules - incl. a box equal to an anchor and a box that
+    overlaps nothing); regression targets within 1e-6 (log)."""
+    import importlib.util
+    import os
+    from hmd_ego_pose_amd.training import anchor_targets
+    from oracle import train_ref as T
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("mgt", os.path.join(here, "golden", "make_golden_targets.py"))
+    mgt = importlib.util.module_from_spec(spec); spec.loader.exec_module(mgt)
+    anchors, _ = api["D"].anchors_for_size(256)
+    cs = mgt.cases(anchors)
+    shapes = [c[1] for c in cs]; boxes = [c[2] for c in cs]; labels = [c[3] for c in cs]; tts = [c[4].astype(np.float32) for c in cs]
+    coords = [c[5].astype(np.float32) for c in cs]
+    want = T.anchor_targets(anchors, shapes, boxes, labels, tts, coords, 1)
+    got = anchor_targets(torch.from_numpy(anchors).cuda(), boxes, labels, tts, coords, [s_[:2] for s_ in shapes], 1)
+    names = ("labels", "regression", "transformation", "coords")
+    for n_, g, w in zip(names, got, want):
+        g = g.cpu().numpy()
+        assert g.shape == w.shape, n_
+        assert np.array_equal(g[..., -1], w[..., -1]), f"{n_}: anchor states differ"
+        if n_ == "regression":
+            assert np.allclose(g[..., :4], w[..., :4], rtol=1e-6, atol=1e-6)
+        else:
+            assert np.array_equal(g, w), n_
+    st = got[1][..., -1].cpu().numpy()
+    assert (st == 1).sum() > 0 and (st == -1).sum() > 0 and st[2].max() <= 0          # image 2 has no boxes: nothing positive
