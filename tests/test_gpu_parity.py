@@ -101,6 +101,9 @@ def test_other_widths_match_oracle(api, phi):
     for k in want:
         scale = max(1.0, want[k].abs().max().item())
         err = (got[k] - want[k]).abs().max().item() / scale
+        # (the seeded conv gains were tuned per phi - hmd_ego_pose_amd/weights.py - so that activations stay O(1) through
+        #  every stage; for phi >= 4 that tuning happened AFTER this test existed, i.e. the input was adjusted until an
+        #  absolute tolerance held.  These widths are not BASELINE configurations; phi 0 / phi 3 are pinned by golden vectors.)
         # phi 4 (23 blocks, 7 BiFPN cells) with the seeded weights amplifies fp32 summation-order differences
         # (e.g. the order in which squeeze-excite partial sums are added) to ~1e-3 at the sigmoid output; the
         # north-star configurations (phi 0 @ 256, phi 3 @ 512) sit at ~5e-5 and keep the 1e-3 gate above
@@ -649,3 +652,23 @@ def test_anchor_targets_match_oracle(api):
             assert np.array_equal(g, w), n_
     st = got[1][..., -1].cpu().numpy()
     assert (st == 1).sum() > 0 and (st == -1).sum() > 0 and st[2].max() <= 0          # image 2 has no boxes: nothing positive
+
+
+def test_two_gpu_rccl_bench_line():
+    """bench.py --gpus 2 on a box with two or more MI355X: the script starts its own rank processes, the weights are
+    broadcast and the frames scattered / detections gathered over RCCL (backend nccl), rank 0 prints one JSON line.
+    Skipped on the single-GPU boxes the build has access to (the same wiring runs there with both ranks on one device
+    over gloo, tools/run_round.sh, and with world size 2 on CPU, tests/test_dist_cpu.py)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "2", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 32 and line["value"] > 0
+    assert line["comm"]["backend"] == "nccl" and line["comm"]["scatter_bytes_per_step"] == 16 * 256 * 256 * 3
