@@ -23,6 +23,14 @@
 #define CHAIN_THREADS 1024
 #define CHAIN_WAVES 16
 
+// profiling build (make trace): wave 0 of every workgroup stamps s_memrealtime (100 MHz) at the phase boundaries
+#ifdef HEP_MBF_TRACE
+__device__ unsigned long long* g_chain_trace = nullptr;
+#define CSTAMP() do { if (g_chain_trace && tid == 0 && nst < 60) st_buf[nst++] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define CSTAMP()
+#endif
+
 namespace {
 
 typedef bf16_t T;
@@ -73,6 +81,10 @@ __global__ __launch_bounds__(CHAIN_THREADS) void chain_kernel(ChainArgs a) {
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
   int cgsh = 0; while ((1 << cgsh) < CG) cgsh++;
   const int cg = tid & ((1 << cgsh) - 1), prow = tid >> cgsh, pstride = CHAIN_THREADS >> cgsh;
+#ifdef HEP_MBF_TRACE
+  unsigned long long st_buf[60]; int nst = 0;
+#endif
+  CSTAMP();
 
   // ---- 1. one burst: node descriptors, all weights and all external maps -> LDS.  Every load is issued before the
   //         first LDS store that waits for it, so the whole prologue is about one memory round trip. ----
@@ -127,13 +139,22 @@ __global__ __launch_bounds__(CHAIN_THREADS) void chain_kernel(ChainArgs a) {
     }
   }
   __syncthreads();
+  CSTAMP();
 
   // ---- 2. the nodes, out of LDS (descriptors included); pixel
   //         indices are split with a reciprocal multiply (a run-time integer division is ~30 instructions on the one
   //         item a lane has per phase). ----
 #pragma unroll 1      // a real loop: the body runs once per node, unrolled it would be fetched cold every time (measured +20 %)
   for (int n = 0; n < a.nnodes; n++) {
-    const ChainNode& nd = nd_s[n];
+    // the descriptor is copied to registers once and made wave-uniform (scalar registers): read field by field from LDS
+    // inside the phases it cost a load + wait per use (the gather phase took 2 us of a 3 us node)
+    ChainNode nd;
+    {
+      const uint32_t* sp = reinterpret_cast<const uint32_t*>(&nd_s[n]);
+      uint32_t* dp = reinterpret_cast<uint32_t*>(&nd);
+#pragma unroll
+      for (int i = 0; i < (int)(sizeof(ChainNode) / 4); i++) dp[i] = __builtin_amdgcn_readfirstlane(sp[i]);
+    }
     const int h = nd.h, w = nd.w, hw = h * w;
     const uint32_t w_rcp = (uint32_t)(0x100000000ull / (uint32_t)w) + 1, hs_rcp = (uint32_t)(0x100000000ull / (uint32_t)(w + 2)) + 1;
     T* oslot = slots + nd.out_off;
@@ -177,7 +198,9 @@ __global__ __launch_bounds__(CHAIN_THREADS) void chain_kernel(ChainArgs a) {
         }
         Vec8<true>::store(halo, (int64_t)pos * CH + cg * 8, v);
       }
+    CSTAMP();
     __syncthreads();
+    CSTAMP();
     // depthwise 3x3 -> MFMA operand tile [pixels][C]; rows beyond the map are zeroed (their products are discarded)
     if (cg < CG)
       for (int p = prow; p < ((hw + 15) & ~15); p += pstride) {
@@ -196,7 +219,9 @@ __global__ __launch_bounds__(CHAIN_THREADS) void chain_kernel(ChainArgs a) {
         }
         Vec8<true>::store(atile, (int64_t)p * CH + cg * 8, acc);
       }
+    CSTAMP();
     __syncthreads();
+    CSTAMP();
     // pointwise: D[n, pixel] = W[n, :] . tile[pixel, :]; (m-tile, n-tile) pairs dealt to the waves; lane ends with 4
     // consecutive channels of one pixel -> its slot in LDS
     const int mt_n = (hw + 15) >> 4, nt_n = C >> 4, ksteps = (C + KSTEP - 1) / KSTEP;
@@ -220,13 +245,30 @@ __global__ __launch_bounds__(CHAIN_THREADS) void chain_kernel(ChainArgs a) {
         Vec8<true>::store4(oslot, (int64_t)m * C + nn, v);
       }
     }
+    CSTAMP();
     __syncthreads();
+    CSTAMP();
     // the finished map leaves as full 16-byte vectors; nobody in this launch reads it from global memory
     if (cg < CG)
       for (int p = prow; p < hw; p += pstride)
         *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(nd.out) + ((int64_t)b * hw + p) * C + cg * 8) = *reinterpret_cast<const u32x4*>(oslot + (int64_t)p * C + cg * 8);
+    CSTAMP();
   }
+#ifdef HEP_MBF_TRACE
+  if (g_chain_trace && tid == 0) { for (int i = 0; i < 60; i++) g_chain_trace[(size_t)b * 64 + i] = i < nst ? st_buf[i] : 0; g_chain_trace[(size_t)b * 64 + 63] = (unsigned long long)nst; }
+#endif
 }
+
+#ifdef HEP_MBF_TRACE
+extern "C" int hep_dbg_chain_trace(unsigned long long* host, int nblocks, int enable) {
+  static unsigned long long* buf = nullptr;
+  if (!buf) { if (hipMalloc((void**)&buf, 4096 * 64 * 8) != hipSuccess) return -1; hipMemset(buf, 0, 4096 * 64 * 8); }
+  unsigned long long* p = enable ? buf : nullptr;
+  hipMemcpyToSymbol(HIP_SYMBOL(g_chain_trace), &p, sizeof p);
+  if (host) { hipDeviceSynchronize(); hipMemcpy(host, buf, (size_t)nblocks * 64 * 8, hipMemcpyDeviceToHost); }
+  return 0;
+}
+#endif
 
 int chain_prepare(void) {
   return hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024) == hipSuccess ? 0 : -1;
