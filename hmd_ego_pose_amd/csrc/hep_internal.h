@@ -30,6 +30,7 @@ struct PwArgs {
   // scale[k] = sigmoid(we[k,:] . hidden + be[k]) for the images its rows belong to (k_pw.hip)
   const float* hpart; const float* se_br; const void* se_we /*[K][sqp], session dtype*/; const float* se_be;
   int se_rows, sq, sqp, se_nimg; float inv_hw;
+  int se_from_tensor; const float* se_scale;   // the scale [B][K] was finished by se_finish_kernel (large K x sq): only copied to LDS
   const void* res;     // [M,N] residual (nullable)
   void* out;
   int M, K, N, tilesN; // tilesN = ceil(N/16); W holds tilesN*16 rows
@@ -53,6 +54,13 @@ struct DwArgs {
   int B, H, W, C, Ho, Wo, k, s, pad_t, pad_l, act, bf16, TW, blocks_per_image;
   uint32_t cg_magic, sw_magic, c_magic;   // reciprocals for C/8, strips per row and C (filled in by launch_dw)
 };
+
+// ---- squeeze-excite finish as its own launch (blocks whose expand-FC matrix is too large for every project workgroup) ----
+struct SeFinishArgs {
+  const float* hpart; const float* br; const void* we /*[C][sqp] session dtype*/; const float* be; float* scale /*[B][C]*/;
+  int B, C, sq, sqp, rows, bf16; float inv_hw;
+};
+void launch_se_finish(const SeFinishArgs&, hipStream_t);
 
 // ---- fused MBConv front: expand 1x1 (+BN,swish) -> depthwise kxk (+BN,swish) -> SE partial sums ----
 struct MbfArgs {

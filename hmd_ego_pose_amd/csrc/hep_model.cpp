@@ -228,7 +228,7 @@ static bool fold_bn(const Pack& pk, const std::string& p, int c, BnFold* out, st
 // index after the plan is complete: each Op records symbolic references here.
 struct Ref { int op; int field; int seg; int idx; size_t woff; int tensor; };
 enum { F_STEM_W, F_STEM_B, F_STEM_OUT, F_PW_A, F_PW_W, F_PW_B, F_PW_RES, F_PW_OUT, F_DW_IN, F_DW_W, F_DW_B,
-       F_DW_OUT, F_DW_PART, F_DW_WR, F_MBF_IN, F_MBF_WE, F_MBF_BE, F_MBF_WDW, F_MBF_BDW, F_MBF_OUT, F_MBF_PART, F_MBF_WR, F_MBF_WESCALE, F_PW_WSCALE, F_PW_HPART, F_PW_SEBR, F_PW_SEWE, F_PW_SEBE, F_POOL_IN, F_POOL_OUT, F_PWG_A, F_PWG_W, F_PWG_B, F_PWG_OUT,
+       F_DW_OUT, F_DW_PART, F_DW_WR, F_MBF_IN, F_MBF_WE, F_MBF_BE, F_MBF_WDW, F_MBF_BDW, F_MBF_OUT, F_MBF_PART, F_MBF_WR, F_MBF_WESCALE, F_PW_WSCALE, F_PW_SESCALE, F_SE_HPART, F_SE_SCALE, F_SE_BR, F_SE_WE, F_SE_BE, F_PW_HPART, F_PW_SEBR, F_PW_SEWE, F_PW_SEBE, F_POOL_IN, F_POOL_OUT, F_PWG_A, F_PWG_W, F_PWG_B, F_PWG_OUT,
        F_SEG_SRC, F_SEG_WDW, F_SEG_WPW, F_SEG_BIAS, F_SEG_OUT, F_CH_EXT_SRC, F_CH_EXT_STORE, F_CH_NODE_OUT, F_CH_WBLOB };
 
 struct Planner {
@@ -256,7 +256,7 @@ struct Planner {
   }
   int new_op(OpKind k, const std::string& name) {
     Op o; memset(&o.stem, 0, sizeof o.stem); memset(&o.pw, 0, sizeof o.pw); memset(&o.dw, 0, sizeof o.dw);
-    memset(&o.pool, 0, sizeof o.pool); memset(&o.sep, 0, sizeof o.sep); memset(&o.mbf, 0, sizeof o.mbf); memset(&o.pwg, 0, sizeof o.pwg); memset(&o.chain, 0, sizeof o.chain);
+    memset(&o.pool, 0, sizeof o.pool); memset(&o.sep, 0, sizeof o.sep); memset(&o.mbf, 0, sizeof o.mbf); memset(&o.pwg, 0, sizeof o.pwg); memset(&o.chain, 0, sizeof o.chain); memset(&o.se, 0, sizeof o.se);
     o.kind = k; o.name = name;
     s->ops.push_back(o);
     return (int)s->ops.size() - 1;
@@ -280,34 +280,58 @@ struct Planner {
       for (int k = 0; k < K; k++) wf[(size_t)n * K + k] = w->data[(size_t)n * K + k] * sc;
       bf[n] = (cb ? cb->data[n] : 0.f) * sc + sh;
     }
-    const int out_t = tensor(out_name, H, W, N);
-    const int op = new_op(OP_PW, name);
-    Op& o = s->ops[op];
-    o.pw.K = K; o.pw.N = N; o.pw.tilesN = tilesN; o.pw.HW = HW; o.pw.act = act; o.pw.bf16 = s->dtype;
     // tile shape: as many n-tiles per wave as fit (<= 8) so the activation rows are streamed
     // as few times as possible; two m-tiles per wave when the layer has rows to spare
+    int pmode, pMT, pNT;
+    const int64_t Mmax = (int64_t)HW * s->lane_batch;      // rows one launch sees (one lane of the batch)
     {
-      const int64_t Mmax = (int64_t)HW * s->lane_batch;      // rows one launch sees (one lane of the batch)
       const int64_t strips = (Mmax + 15) / 16;             // 16-row strips
       const int ksteps = (K + (s->dtype ? 32 : 16) - 1) / (s->dtype ? 32 : 16);
       auto clampi = [](int64_t v, int lo, int hi) { return (int)std::max<int64_t>(lo, std::min<int64_t>(hi, v)); };
       if (Mmax >= 16384) {          // big maps: waves along M, >= 256 workgroups anyway
         const int chunks = (tilesN + 7) / 8;
-        o.pw.mode = 0; o.pw.NT = (tilesN + chunks - 1) / chunks;
-        o.pw.MT = (Mmax >= 65536 && o.pw.NT <= 4) ? 2 : 1;
+        pmode = 0; pNT = (tilesN + chunks - 1) / chunks;
+        pMT = (Mmax >= 65536 && pNT <= 4) ? 2 : 1;
       } else if (ksteps >= 8) {     // small maps, deep K (project): split K over the 4 waves
-        o.pw.mode = 2; o.pw.MT = 1; o.pw.NT = clampi(strips * tilesN / 256, 1, std::min(8, tilesN));
+        pmode = 2; pMT = 1; pNT = clampi(strips * tilesN / 256, 1, std::min(8, tilesN));
       } else {                      // small maps, wide N (expand / lateral): waves side by side in N
-        o.pw.mode = 1; o.pw.MT = 1; o.pw.NT = clampi(strips * tilesN / (4 * 256), 1, std::min(8, (tilesN + 3) / 4));
+        pmode = 1; pMT = 1; pNT = clampi(strips * tilesN / (4 * 256), 1, std::min(8, (tilesN + 3) / 4));
       }
       // Two m-tiles per wave in modes 1/2 (every weight fragment feeds two MFMAs, half the weight re-reads
       // from L2): no effect on a single batch in flight, but -2.5 % on the step with 4 batches in flight and
       // at batch 64, where these layers are bound by L2 traffic and not by latency.  HEP_PW_MT2=0 disables.
       {
         const char* e = getenv("HEP_PW_MT2");
-        if (o.pw.mode != 0 && strips >= 8 && !(e && atoi(e) == 0)) { o.pw.MT = 2; o.pw.NT = std::min(o.pw.NT, 4); }
+        if (pmode != 0 && strips >= 8 && !(e && atoi(e) == 0)) { pMT = 2; pNT = std::min(pNT, 4); }
       }
     }
+    // Squeeze-excite: finished in this GEMM's prologue (no launch) while the K x sq expand-FC matrix re-read by every
+    // workgroup stays below HEP_SE_MAXMB (default 4) MB per launch; beyond that a small launch finishes it once per
+    // image (k_dw.hip).  Measured at phi 0, batch 16 (same box, 2 x 300 steps): threshold 1000 / 12 / 8 / 4 / 0 MB ->
+    // 40.7k / 41.0k / 41.3k / 41.7k / 41.8k frames/s with four batches in flight and 20.9k / 20.9k / 20.9k / 20.9k /
+    // 20.6k with one (55 / 59 / 61 / 65 / 71 launches): the redundant L2 traffic of the prologue costs throughput on the
+    // late blocks, the extra launches cost latency on the early ones.  phi 3 @ 512: 3.20k / 3.31k (24 MB) / 3.39k (0).
+    int scale_t = -1;
+    if (se) {
+      const int rows_wg = pmode == 0 ? 64 * pMT : 16 * pMT, per_n = pmode == 1 ? 4 * pNT : pNT;
+      const double wgs = (double)((Mmax + rows_wg - 1) / rows_wg) * ((tilesN + per_n - 1) / per_n);
+      static const double maxmb = getenv("HEP_SE_MAXMB") ? atof(getenv("HEP_SE_MAXMB")) : 4.0;
+      if (wgs * K * se->sqp * es() > maxmb * 1e6) {
+        scale_t = tensor(name + ".se_scale", 1, 1, K, true);
+        const int sop = new_op(OP_SE, name.substr(0, name.find('.')) + ".se");
+        Op& so = s->ops[sop];
+        so.se.C = K; so.se.sq = se->sq; so.se.sqp = se->sqp; so.se.rows = se->rows; so.se.bf16 = s->dtype; so.se.inv_hw = se->inv_hw;
+        tref(sop, F_SE_HPART, se->hpart_t, false); tref(sop, F_SE_SCALE, scale_t, true);
+        wref(sop, F_SE_BR, se->br); wref(sop, F_SE_WE, se->we); wref(sop, F_SE_BE, se->be);
+        so.act_bytes_per_image = ((double)se->rows * se->sqp + K) * 4; so.weight_bytes = (double)K * se->sq * es() + ((double)K + se->sq) * 4;
+        so.flops_per_image = 2.0 * K * se->sq;
+      }
+    }
+    const int out_t = tensor(out_name, H, W, N);
+    const int op = new_op(OP_PW, name);
+    Op& o = s->ops[op];
+    o.pw.K = K; o.pw.N = N; o.pw.tilesN = tilesN; o.pw.HW = HW; o.pw.act = act; o.pw.bf16 = s->dtype;
+    o.pw.mode = pmode; o.pw.MT = pMT; o.pw.NT = pNT;
     tref(op, F_PW_A, in_t, false); tref(op, F_PW_OUT, out_t, true);     // (reads[0] is the GEMM's activation operand: fp8 calibration)
     if (quant && s->dtype == 2) {     // fp8 session: e4m3 weights, one scale per output channel behind the BN fold
       std::vector<float> sc;
@@ -319,7 +343,13 @@ struct Planner {
     o.act_bytes_per_image = ((double)HW * K + (double)HW * N * (res_t >= 0 ? 2 : 1)) * es();
     o.weight_bytes = (double)N * K * (o.pw.fp8 ? 1.0 : es());
     o.flops_per_image = 2.0 * HW * K * N;
-    if (se) {
+    if (se && scale_t >= 0) {
+      o.pw.se_from_tensor = 1; o.pw.sq = se->sq; o.pw.sqp = se->sqp;
+      tref(op, F_PW_SESCALE, scale_t, false);
+      const int rows_wg = o.pw.mode == 0 ? 64 * o.pw.MT : 16 * o.pw.MT;
+      o.pw.se_nimg = HW % rows_wg == 0 ? 1 : (rows_wg + HW - 1) / HW + 1;
+      o.act_bytes_per_image += (double)K * 4;
+    } else if (se) {
       tref(op, F_PW_HPART, se->hpart_t, false);
       wref(op, F_PW_SEBR, se->br); wref(op, F_PW_SEWE, se->we); wref(op, F_PW_SEBE, se->be);
       o.pw.se_rows = se->rows; o.pw.sq = se->sq; o.pw.sqp = se->sqp; o.pw.inv_hw = se->inv_hw;
@@ -1040,6 +1070,12 @@ int build_session(Session* s, const Pack& pack, std::string* err) {
         case F_MBF_WR: o.mbf.se_wr = (const float*)ptr; break;
         case F_MBF_WESCALE: o.mbf.we_scale = (const float*)ptr; break;
         case F_PW_WSCALE: o.pw.wscale = (const float*)ptr; break;
+        case F_PW_SESCALE: o.pw.se_scale = (const float*)ptr; break;
+        case F_SE_HPART: o.se.hpart = (const float*)ptr; break;
+        case F_SE_SCALE: o.se.scale = (float*)ptr; break;
+        case F_SE_BR: o.se.br = (const float*)ptr; break;
+        case F_SE_WE: o.se.we = ptr; break;
+        case F_SE_BE: o.se.be = (const float*)ptr; break;
         case F_POOL_IN: o.pool.in = ptr; break;
         case F_POOL_OUT: o.pool.out = ptr; break;
         case F_PWG_A: o.pwg.seg[r.seg].A = ptr; break;

@@ -241,6 +241,66 @@ void launch_dw(const DwArgs& a_, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// squeeze-excite finish as its own launch: hidden = swish(inv_hw * sum_rows hpart + br), scale = sigmoid(we . hidden + be)
+// (reference efficientnet/model.py:90-93).  Only for blocks whose expand-FC matrix (C x sq) is too large to be re-read by
+// every workgroup of the project GEMM (phi >= 3: 2304 x 96); everywhere else the project GEMM finishes the SE in its
+// prologue (k_pw_impl.h).  grid = (B, SE_SPLIT): every block rebuilds the (tiny) hidden vector and produces one slice
+// of the channels; fixed summation order.
+// ------------------------------------------------------------------------------------------------
+#define SE_SPLIT 8
+template <bool BF16>
+__global__ __launch_bounds__(256) void se_finish_kernel(SeFinishArgs a) {
+  extern __shared__ float se_sm[];          // hidden [sqp] | helper-group row sums [G][sqp]
+  typedef typename Vec8<BF16>::elem T;
+  float* hid_s = se_sm;
+  float* red_s = se_sm + a.sqp;
+  const int b = blockIdx.x, sqp = a.sqp, sq = a.sq;
+  const int G = max(1, 256 / sqp);
+  const int grp = threadIdx.x / sqp, j = threadIdx.x - grp * sqp;
+  if (grp < G && j < sq) {
+    const float* hp = a.hpart + (int64_t)b * a.rows * sqp + j;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int row = grp;
+    for (; row + 3 * G < a.rows; row += 4 * G) {
+      s0 += hp[(int64_t)row * sqp]; s1 += hp[(int64_t)(row + G) * sqp]; s2 += hp[(int64_t)(row + 2 * G) * sqp]; s3 += hp[(int64_t)(row + 3 * G) * sqp];
+    }
+    for (; row < a.rows; row += G) s0 += hp[(int64_t)row * sqp];
+    red_s[grp * sqp + j] = (s0 + s1) + (s2 + s3);
+  }
+  __syncthreads();
+  if (threadIdx.x < sqp) {
+    float h = 0.f;
+    if (threadIdx.x < sq) {
+      float sacc = 0.f;
+      for (int q = 0; q < G; q++) sacc += red_s[q * sqp + threadIdx.x];
+      h = swishf(fmaf(sacc, a.inv_hw, a.br[threadIdx.x]));
+    }
+    hid_s[threadIdx.x] = h;
+  }
+  __syncthreads();
+  const int per = ((a.C + SE_SPLIT - 1) / SE_SPLIT + 7) & ~7;
+  const int c0 = blockIdx.y * per, c1 = min(a.C, c0 + per);
+  const T* WE = reinterpret_cast<const T*>(a.we);
+  for (int k = c0 + threadIdx.x; k < c1; k += 256) {
+    float e0 = 0.f, e1 = 0.f;
+    for (int v = 0; v < sqp; v += 8) {
+      float w[8];
+      Vec8<BF16>::load(WE, (int64_t)k * sqp + v, w);
+      const f32x4 h0 = *reinterpret_cast<const f32x4*>(hid_s + v), h1 = *reinterpret_cast<const f32x4*>(hid_s + v + 4);
+      // (the same pairing of partial sums as the prologue of the project GEMM: even / odd hidden units)
+      e0 = fmaf(w[0], h0[0], e0); e1 = fmaf(w[1], h0[1], e1); e0 = fmaf(w[2], h0[2], e0); e1 = fmaf(w[3], h0[3], e1);
+      e0 = fmaf(w[4], h1[0], e0); e1 = fmaf(w[5], h1[1], e1); e0 = fmaf(w[6], h1[2], e0); e1 = fmaf(w[7], h1[3], e1);
+    }
+    a.scale[(int64_t)b * a.C + k] = sigmoidf((e0 + e1) + a.be[k]);
+  }
+}
+void launch_se_finish(const SeFinishArgs& a, hipStream_t s) {
+  const size_t lds = ((size_t)a.sqp + 256 + a.sqp) * sizeof(float);
+  if (a.bf16) hipLaunchKernelGGL(se_finish_kernel<true>, dim3(a.B, SE_SPLIT), dim3(256), lds, s, a);
+  else hipLaunchKernelGGL(se_finish_kernel<false>, dim3(a.B, SE_SPLIT), dim3(256), lds, s, a);
+}
+
+// ------------------------------------------------------------------------------------------------
 // MaxPool2dStaticSamePadding(3,2): the pad value is ZERO, not -inf (reference
 // efficientnet/utils_extra.py:72-86), so windows that overhang the border take max(...,0).
 // ------------------------------------------------------------------------------------------------

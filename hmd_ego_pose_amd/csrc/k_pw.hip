@@ -15,6 +15,7 @@ extern template void launch_pw_prec<2>(const PwArgs&, hipStream_t);
 // squeeze-excite prologue variant of a launch (also names the device function, hep_kernel_symbol)
 int pw_se_variant(const PwArgs& a) {
   if (a.sq <= 0 || a.act == ACT_SWISH) return 0;          // (sq is set by the planner for project convs only)
+  if (a.se_from_tensor) return 3;
   return (a.K > 256 || a.sqp / (a.bf16 ? 8 : 4) > 2) ? 2 : 1;
 }
 

@@ -53,7 +53,9 @@ struct Step {
 // branch per output element
 // SEV: squeeze-excite prologue variant - 0 none (expand / lateral convs), 1 one weight row x two vectors in flight
 // per lane (K <= 256: the project convs on the big maps, which need their occupancy), 2 five rows x six vectors
-// (deep K on the small maps).  A template parameter because the rows in flight set the kernel's register count.
+// (deep K on the small maps), 3 the scale vector was finished by se_finish_kernel (k_dw.hip) and is only copied into LDS
+// (blocks whose K x sq weight matrix is too large to be re-read by every workgroup: phi >= 3).  A template parameter
+// because the rows in flight set the kernel's register count.
 template <int PREC, int MT, int NT, int MODE, int ACT, int SEV>
 __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
   constexpr bool BF16 = PREC != 0, F8 = PREC == 2;
@@ -121,7 +123,15 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
   extern __shared__ __attribute__((aligned(16))) float se_s[];
   constexpr bool SE = SEV != 0;
   int img0 = 0;
-  if constexpr (SE) {
+  if constexpr (SEV == 3) {
+    constexpr int ROWS = MODE == 0 ? 64 * MT : 16 * MT;
+    const int mfirst = mblk * ROWS, mlast = min(M, mfirst + ROWS) - 1;
+    img0 = mfirst / a.HW;
+    const int nimg = mlast / a.HW - img0 + 1;
+    for (int i = threadIdx.x * 4; i < nimg * K; i += 256 * 4)          // K is a multiple of 8
+      *reinterpret_cast<f32x4*>(se_s + i) = *reinterpret_cast<const f32x4*>(a.se_scale + (int64_t)img0 * K + i);
+    __syncthreads();
+  } else if constexpr (SE) {
     constexpr int ROWS = MODE == 0 ? 64 * MT : 16 * MT;
     constexpr int JV = BF16 ? 8 : 4;              // hidden units per 16-byte weight vector
     constexpr int RB = SEV == 2 ? 5 : 1, VB = SEV == 2 ? 6 : 2;   // weight rows x vectors in flight per lane
@@ -335,6 +345,7 @@ static void launch_nt(const PwArgs& a, dim3 grid, hipStream_t s) {
 #define CASE(n) case n: if (a.act == ACT_SWISH) hipLaunchKernelGGL((pw_gemm_kernel<PREC, MT, n, MODE, ACT_SWISH, 0>), grid, dim3(256), 0, s, a); \
                 else if (sev == 0) hipLaunchKernelGGL((pw_gemm_kernel<PREC, MT, n, MODE, ACT_NONE, 0>), grid, dim3(256), 0, s, a); \
                 else if (sev == 1) hipLaunchKernelGGL((pw_gemm_kernel<PREC, MT, n, MODE, ACT_NONE, 1>), grid, dim3(256), lds, s, a); \
+                else if (sev == 3) hipLaunchKernelGGL((pw_gemm_kernel<PREC, MT, n, MODE, ACT_NONE, 3>), grid, dim3(256), lds, s, a); \
                 else hipLaunchKernelGGL((pw_gemm_kernel<PREC, MT, n, MODE, ACT_NONE, 2>), grid, dim3(256), lds, s, a); break;
     CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
 #undef CASE
