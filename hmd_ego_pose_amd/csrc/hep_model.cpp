@@ -424,7 +424,8 @@ struct Planner {
     // output tile side of the fused front: 16 on the stride-1 layers of 16x16 / 32x32 maps (the whole 16x16 map per
     // workgroup: no halo re-expansion, a quarter of the workgroups and of their fixed staging / drain latency), else 8.
     // HEP_MBF_TS=8 forces the small tile (A/B measurements, parity test of the alternative plan).
-    int ts = (b.stride == 1 && b.expand && Ho >= 16 && Ho <= 32) ? 16 : 8;
+    static const int ts16_maxh = getenv("HEP_MBF_TS16_MAXH") ? atoi(getenv("HEP_MBF_TS16_MAXH")) : 32;     // A/B knob
+    int ts = (b.stride == 1 && b.expand && Ho >= 16 && Ho <= ts16_maxh) ? 16 : 8;
     if (const char* e = getenv("HEP_MBF_TS")) if (atoi(e) == 8) ts = 8;
     int max_in = mbf_max_inside(Hin, Win, b.k, b.stride, pt, pl, ts);   // rows of the compact input tile in LDS
     if (ts == 16 && mbf_lds_layout(b.cin, 64, b.k, b.stride, s->dtype, b.expand, max_in, ts, nullptr) > 159 * 1024 &&
