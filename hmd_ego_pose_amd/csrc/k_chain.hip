@@ -224,7 +224,7 @@ __global__ __launch_bounds__(CHAIN_THREADS) void chain_kernel(ChainArgs a) {
     CSTAMP();
     // pointwise: D[n, pixel] = W[n, :] . tile[pixel, :]; (m-tile, n-tile) pairs dealt to the waves; lane ends with 4
     // consecutive channels of one pixel -> its slot in LDS
-    const int mt_n = (hw + 15) >> 4, nt_n = C >> 4, ksteps = (C + KSTEP - 1) / KSTEP;
+    const int mt_n = (hw + 15) >> 4, nt_n = (C + 15) >> 4, ksteps = (C + KSTEP - 1) / KSTEP;      // (widths like 88: the last n-tile is half used)
     for (int pair = wave; pair < mt_n * nt_n; pair += CHAIN_WAVES) {
       const int mt = (int)__umulhi((uint32_t)pair, (uint32_t)(0x100000000ull / (uint32_t)nt_n) + 1), nt = pair - mt * nt_n;
       const int m = mt * 16 + r;
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(CHAIN_THREADS) void chain_kernel(ChainArgs a) {
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf), __builtin_bit_cast(bf16x8, xa), acc, 0, 0, 0);
       }
       const int nn = nt * 16 + 4 * g;
-      if (m < hw) {
+      if (m < hw && nn < C) {
         const f32x4 bias = *reinterpret_cast<const f32x4*>(bias_s + nn);
         float v[4];
 #pragma unroll
