@@ -129,12 +129,9 @@ def test_ragged_tiles_match_oracle(api, size, batch):
         err = (got[k] - want[k]).abs().max().item() / max(1.0, want[k].abs().max().item())
         assert err <= 1e-3, f"size {size} {k}: {err:.3e}"
     s.close()
-    s = api["Session"](sd, phi, size, batch, "bf16")
-    out = s.forward(x.cuda())
-    torch.cuda.synchronize()
-    for name, a_, b_ in zip(("regression", "classification", "rotation", "translation_raw", "hand"), out[1:], list(want.values())[:5]):
-        assert torch.isfinite(a_).all(), name
-    s.close()
+    # bf16: the same stage-by-stage gate as the BASELINE configurations (odd maps exercise the LDS-resident BiFPN chains
+    # with 6x6 / 3x3 and 10x10 / 5x5 levels: one-sided pool padding, nearest up-sampling of odd sizes)
+    _teacher_forced_bf16(api, sd, phi, size, batch, x, api["R"].forward(sd, x, phi))
 
 
 HEADS = ("regression", "classification", "rotation", "translation_raw", "hand")
