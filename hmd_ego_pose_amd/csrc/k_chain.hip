@@ -20,8 +20,10 @@
 #include "hep_dev.h"
 #include "hep_internal.h"
 
+#ifndef CHAIN_THREADS
 #define CHAIN_THREADS 1024
-#define CHAIN_WAVES 16
+#endif
+#define CHAIN_WAVES (CHAIN_THREADS / 64)
 
 // profiling build (make trace): wave 0 of every workgroup stamps s_memrealtime (100 MHz) at the phase boundaries
 #ifdef HEP_MBF_TRACE
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(CHAIN_THREADS) void chain_kernel(ChainArgs a) {
     if (tid < ndw) dv = reinterpret_cast<const uint32_t*>(a.nodes)[tid];
     // the chain's weights: one contiguous blob already in the LDS layout (per node [9*C] f32 depthwise | [C] f32 bias |
     // [C][C+PAD] bf16 pointwise rows)
-    constexpr int WB = 4;
+    constexpr int WB = 4096 / CHAIN_THREADS;
     const int wvecs = (int)(((size_t)a.nconv * a.wnode_bytes) >> 4);
     u32x4 wv[WB];
 #pragma unroll
