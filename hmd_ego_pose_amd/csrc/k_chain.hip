@@ -85,6 +85,7 @@ __global__ __launch_bounds__(CHAIN_THREADS) void chain_kernel(ChainArgs a) {
   const int cg = tid & ((1 << cgsh) - 1), prow = tid >> cgsh, pstride = CHAIN_THREADS >> cgsh;
 #ifdef HEP_MBF_TRACE
   unsigned long long st_buf[60]; int nst = 0;
+  const unsigned long long clk0 = __builtin_amdgcn_s_memtime();
 #endif
   CSTAMP();
 
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(CHAIN_THREADS) void chain_kernel(ChainArgs a) {
     CSTAMP();
   }
 #ifdef HEP_MBF_TRACE
-  if (g_chain_trace && tid == 0) { for (int i = 0; i < 60; i++) g_chain_trace[(size_t)b * 64 + i] = i < nst ? st_buf[i] : 0; g_chain_trace[(size_t)b * 64 + 63] = (unsigned long long)nst; }
+  if (g_chain_trace && tid == 0) { for (int i = 0; i < 60; i++) g_chain_trace[(size_t)b * 64 + i] = i < nst ? st_buf[i] : 0; g_chain_trace[(size_t)b * 64 + 63] = (unsigned long long)nst; g_chain_trace[(size_t)b * 64 + 62] = __builtin_amdgcn_s_memtime() - clk0; }
 #endif
 }
 

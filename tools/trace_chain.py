@@ -17,3 +17,4 @@ buf = np.zeros((B, 64), np.uint64); f(buf.ctypes.data, B, 0)
 n = int(buf[0, 63]); t = buf[:, :n].astype(np.int64); rel = (t - t[:, :1]) * 10e-3
 print("stamps per block", n, "; mean us since kernel start:"); print(np.round(rel.mean(axis=0), 2))
 print("deltas:", np.round(np.diff(rel.mean(axis=0)), 2))
+print("shader clock during the kernel: %.2f GHz" % float((buf[:, 62].astype(np.float64) / ((t[:, -1] - t[:, 0]) * 10.0)).mean()))
