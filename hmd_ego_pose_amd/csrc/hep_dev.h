@@ -106,6 +106,8 @@ template <> struct Vec8<false> {
 // for any grid size.
 // two-dimensional grids: the hardware deals the LINEAR block id (x + y * gx) round-robin, so the remap works on that
 __device__ __forceinline__ void xcd_remap2(int bx, int by, int gx, int gy, int* x, int* y);
+// x / d with rcp = rcp_u32(d) (hep_internal.h): exact for x * d < 2^32
+__device__ __forceinline__ int udiv_rcp(int x, uint32_t rcp) { return rcp ? (int)__umulhi((uint32_t)x, rcp) : x; }
 __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
   int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
   int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;

@@ -5,6 +5,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// exact unsigned division by a launch-time constant: rcp_u32(d) on the host, udiv_rcp(x, rcp) in the kernel.
+// floor(x / d) == mulhi(x, floor(2^32 / d) + 1) whenever x * d < 2^32 (grid indices and tile counts here); d == 1 is
+// flagged with rcp == 0.  A run-time integer division costs ~30 VALU instructions per wave.
+static inline uint32_t rcp_u32(uint32_t d) { return d <= 1 ? 0u : (uint32_t)(0x100000000ull / d) + 1u; }
+
 #define HEP_MAX_SRC 3
 #define SEP_MAX_TILES_N 6    // n-tiles (16 columns) per head-output sepconv segment; wider headers are split into segments
 #define SEP_MAX_TILES_MAP 24 // n-tiles of a map-producing segment (BiFPN width <= 384): never split
@@ -79,6 +84,8 @@ struct MbfArgs {
   size_t off_e, off_we, off_w, lds_bytes;
   int fp8; const float* we_scale; float a_scale;   // fp8 sessions: e4m3 expand weights (rows padded to 16 bytes), per-channel / per-tensor scales
   int trace;           // profiling builds (-DHEP_MBF_TRACE): this launch writes its phase time stamps
+  int chunks, tiles_x;                          // filled by launch_mbf: channel chunks per tile, tiles per row
+  uint32_t chunks_rcp, tiles_x_rcp, gx_rcp;     // rcp_u32() of chunks, tiles_x, gridDim.x (device: udiv_rcp)
 };
 
 // ---- 3x3 s2 max-pool, TF-SAME with ZERO padding (utils_extra.py:72-86) ----

@@ -39,13 +39,18 @@
 // boundaries of the LAST mbf launch, read back with hep_dbg_mbf_trace() - profiling builds only.
 #ifdef HEP_MBF_TRACE
 __device__ unsigned long long* g_mbf_trace = nullptr;
+#ifdef HEP_MBF_TRACE_A      // sub-steps of phase A instead of the phase boundaries: 1 kernargs in, 2 loads issued, 3 first data, 4 all parked, 5 barrier
+#define MSTAMP(i) do { if ((i) == 0 || (i) == 6) stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define XSTAMP(i) do { stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
 #define MSTAMP(i) do { stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define XSTAMP(i)
+#endif
 #else
 #define MSTAMP(i)
+#define XSTAMP(i)
 #endif
 
-// exact x / d for x * d < 2^32 with rcp = floor(2^32 / d) + 1
-__device__ __forceinline__ int fast_div_u(int x, uint32_t rcp) { return (int)__umulhi((uint32_t)x, rcp); }
 
 template <bool BF16, int KS, int S, int TS>
 __global__ __launch_bounds__(TS == 16 ? 1024 : 512) void mbf_kernel(MbfArgs a) {
@@ -63,14 +68,18 @@ __global__ __launch_bounds__(TS == 16 ? 1024 : 512) void mbf_kernel(MbfArgs a) {
 #endif
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, g = lane >> 4;
-  const int chunks = (a.Cexp + a.CC - 1) / a.CC;
+  // The prologue below runs in every wave of a latency-bound workgroup: its instruction count is kernel time
+  // (measured with the phase-A stamps: 1250 instructions = 2.6 us before the last staging load was issued).  So every
+  // uniform quotient arrives as a host-made reciprocal, the shifts come from clz, addresses are 32-bit offsets from a
+  // uniform base and the staging loads are unconditional on a clamped address.
+  const int chunks = a.chunks;
   // XCD-aware order: the workgroups of one tile (its channel chunks) all stage the same input pixels; as consecutive
   // LOGICAL blocks they share an XCD and its L2 instead of fetching the tile into up to eight of them
-  int bxl, b;
-  xcd_remap2(blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, &bxl, &b);
-  const int tile = bxl / chunks, chunk = bxl % chunks;
-  const int tiles_x = (a.Wo + TS - 1) / TS;
-  const int oy0 = (tile / tiles_x) * TS, ox0 = (tile % tiles_x) * TS;
+  const int logical = xcd_remap(blockIdx.x + blockIdx.y * gridDim.x, gridDim.x * gridDim.y);
+  const int b = udiv_rcp(logical, a.gx_rcp), bxl = logical - b * (int)gridDim.x;
+  const int tile = udiv_rcp(bxl, a.chunks_rcp), chunk = bxl - tile * chunks;
+  const int tile_y = udiv_rcp(tile, a.tiles_x_rcp);
+  const int oy0 = tile_y * TS, ox0 = (tile - tile_y * a.tiles_x) * TS;
   const int iy0 = oy0 * S - a.pad_t, ix0 = ox0 * S - a.pad_l;     // input coords of tile pixel (0,0)
   const int c0 = chunk * a.CC;                                     // first expanded channel of this block
   const int cc = min(a.CC, a.Cexp - c0);                           // channels of this block (multiple of 8)
@@ -93,100 +102,142 @@ __global__ __launch_bounds__(TS == 16 ? 1024 : 512) void mbf_kernel(MbfArgs a) {
   const int ksteps = (K + KSTEP - 1) / KSTEP;
   const int r0 = max(0, -iy0), r1 = min(PW, a.H - iy0), q0 = max(0, -ix0), q1 = min(PW, a.W - ix0);   // inside rectangle
   const int wi = q1 - q0, n_in = wi * (r1 - r0);
-  const uint32_t wi_rcp = (uint32_t)(0x100000000ull / (uint32_t)wi) + 1;   // uniform: one scalar division per workgroup
-  // (index arithmetic: every divisor below is a compile-time constant or a power of two - a run-time
-  //  integer division costs ~30 VALU instructions and this kernel used to spend most of its issue
-  //  slots on them)
+  // inside pixel m -> (row, column) of the rectangle: m < 2^10 and wi <= 20, so (m + 0.5) / wi stays 0.5 / wi away from
+  // an integer and the 1-ulp reciprocal cannot move the truncation
+  const float wi_inv = __builtin_amdgcn_rcpf((float)wi);
+  auto row_of = [&](int m) { return (int)(((float)m + 0.5f) * wi_inv); };
   // depthwise weights + biases: 16-byte vectors; their loads are issued here, the input-tile / expand-weight
   // loads right behind them, and only then are they parked in LDS - one memory round trip for all of
   // phase A (cc and c0 are multiples of 8)
   constexpr int NDW = (KS * KS * 128 / 4 + MBF_THREADS - 1) / MBF_THREADS;       // CC <= 128
   const int cv = cc >> 2;                                                        // float4 vectors per tap
-  int cvsh = 1; while ((1 << cvsh) < cv) cvsh++;
+  const int cvsh = cv <= 2 ? 1 : 32 - __builtin_clz(cv - 1);
   f32x4 wv[NDW];
+#ifdef HEP_MBF_TRACE_A
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+  XSTAMP(1);
+  const float* wdw_g = a.wdw + c0;
 #pragma unroll
   for (int j = 0; j < NDW; j++) {
     const int i = threadIdx.x + j * MBF_THREADS, tap = i >> cvsh, c4 = i & ((1 << cvsh) - 1);
-    wv[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (tap < KS * KS && c4 < cv) wv[j] = *reinterpret_cast<const f32x4*>(a.wdw + (int64_t)tap * a.Cexp + c0 + c4 * 4);
+    const bool ok = tap < KS * KS && c4 < cv;
+    wv[j] = *reinterpret_cast<const f32x4*>(wdw_g + (ok ? (uint32_t)(tap * a.Cexp + c4 * 4) : 0u));
   }
-  f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int bi = threadIdx.x;                        // threads [0, cv): depthwise bias, [64, 64 + cv): expand bias
-  if (bi < cv) bv = *reinterpret_cast<const f32x4*>(a.bdw + c0 + bi * 4);
-  else if (a.has_expand && bi >= 64 && bi - 64 < cv) bv = *reinterpret_cast<const f32x4*>(a.be + c0 + (bi - 64) * 4);
+  const bool b_dw = bi < cv, b_ex = a.has_expand && bi >= 64 && bi - 64 < cv;
+  const f32x4 bv = *reinterpret_cast<const f32x4*>((b_ex ? a.be : a.bdw) + c0 + (b_dw || b_ex ? (uint32_t)(bi & 63) * 4 : 0u));
   auto park_weights = [&]() {
 #pragma unroll
     for (int j = 0; j < NDW; j++) {
       const int i = threadIdx.x + j * MBF_THREADS, tap = i >> cvsh, c4 = i & ((1 << cvsh) - 1);
       if (tap < KS * KS && c4 < cv) *reinterpret_cast<f32x4*>(wdw_s + tap * a.CC + c4 * 4) = wv[j];
     }
-    if (bi < cv) *reinterpret_cast<f32x4*>(bdw_s + bi * 4) = bv;
-    else if (bi >= 64 && bi - 64 < cv) *reinterpret_cast<f32x4*>(be_s + (bi - 64) * 4) = bv;
+    if (b_dw) *reinterpret_cast<f32x4*>(bdw_s + bi * 4) = bv;
+    else if (b_ex) *reinterpret_cast<f32x4*>(be_s + (bi - 64) * 4) = bv;
   };
   {
     constexpr int NB = BF16 ? 8 : 4;                               // 16-byte vectors (bf16) / 32-byte pairs (fp32) in flight per lane
-    const int kv = K >> 3;                                         // 8-channel vectors per input pixel / weight row
-    const int vecs = a.has_expand ? kv : cc >> 3;
-    const int cbase = a.has_expand ? 0 : c0;
-    T* dst = a.has_expand ? a_s : e_s;
-    const int pitch = a.has_expand ? KP : EP;
-    const int64_t img = (int64_t)b * a.H * a.W * K;
-    // thread -> (row, vector): vectors rounded up to a power of two so the split is a shift and a mask;
-    // rows = the expand-weight rows c0 .. c0 + 16*ntiles, then the PIN input pixels
-    int vsh = 0; while ((1 << vsh) < vecs) vsh++;
+    constexpr int VB = 8 * (int)sizeof(T);                         // bytes of one 8-channel vector
+    const int vecs = a.has_expand ? K >> 3 : cc >> 3;              // 8-channel vectors per staged pixel
+    const unsigned char* in_b = reinterpret_cast<const unsigned char*>(a.in) + (int64_t)b * a.H * a.W * K * (int)sizeof(T);
+    // thread -> (row, vector): vectors rounded up to a power of two so the split is a shift and a mask
+    const int vsh = vecs <= 1 ? 0 : 32 - __builtin_clz(vecs - 1);
     const int v = threadIdx.x & ((1 << vsh) - 1), row0 = threadIdx.x >> vsh, rstride = MBF_THREADS >> vsh;
-    // with an expand stage only the tile pixels INSIDE the image are staged (compact rows mc = ri * wi + ci
-    // of the rectangle [r0,r1) x [q0,q1) of the PW x PW tile) and expanded; the rest of the expanded tile is
-    // the zero padding of the depthwise conv and is written as zeros right here
-    const int n_wrows = a.has_expand ? ntiles * 16 : 0, n_rows = n_wrows + (a.has_expand ? n_in : PIN);
-    const T* Wg = reinterpret_cast<const T*>(a.we) + (int64_t)c0 * K;
-    // fp8 sessions: the expand weights are e4m3, rows padded to K16 = ceil16(K) bytes in memory and K16 + 16 in LDS
-    const unsigned char* Wg8 = reinterpret_cast<const unsigned char*>(a.we) + (int64_t)c0 * K16;
-    const int vecs_w = F8 ? K16 >> 4 : vecs;
     if (a.has_expand) {
+      // rows = the expand-weight rows c0 .. c0 + 16*ntiles, then the tile pixels INSIDE the image (compact rows
+      // m = ri * wi + ci of the rectangle [r0,r1) x [q0,q1) of the PW x PW tile): only those are staged and expanded;
+      // the rest of the expanded tile is the zero padding of the depthwise conv and is written as zeros right here
+      const int n_wrows = ntiles * 16;
+      // fp8 sessions: the expand weights are e4m3, rows padded to K16 = ceil16(K) bytes in memory and K16 + 16 in LDS
+      const int wrow_b = F8 ? K16 : K * (int)sizeof(T), vecs_w = F8 ? K16 >> 4 : vecs, wv_b = F8 ? 16 : VB;
+      const unsigned char* w_b = reinterpret_cast<const unsigned char*>(a.we) + (int64_t)c0 * wrow_b;
+      const int pix0 = (iy0 + r0) * a.W + ix0 + q0;                // first inside pixel of the tile in the image
       const int nv = PIN * EP * (int)sizeof(T) / 16;               // the whole [PIN][EP] tile in 16-byte vectors
       for (int i = threadIdx.x; i < nv; i += MBF_THREADS) reinterpret_cast<u32x4*>(e_s)[i] = (u32x4){0, 0, 0, 0};
-    }
-    for (int base = 0; base < n_rows; base += rstride * NB) {
-      raw_t x0[NB], x1[NB];
+      // weight rows and pixel rows are separate batches (a per-row select between the two address forms compiled to
+      // two branches per load); the first batch of each is in flight before anything is parked
+      constexpr int NH = NB / 2;
+      const bool vok_w = v < vecs_w, vok = v < vecs;
+      const int wstep = rstride * wrow_b;
+      raw_t w0[NH], w1[NH], p0[NH], p1[NH];
+      auto issue_w = [&](int base) {
+        uint32_t off = (uint32_t)((base + row0) * wrow_b + v * wv_b);
 #pragma unroll
-      for (int j = 0; j < NB; j++) {
-        const int row = base + j * rstride + row0;
-        x0[j] = raw_t{}; x1[j] = raw_t{};
-        if (v < (row < n_wrows ? vecs_w : vecs) && row < n_rows) {
-          const T* src = nullptr;
-          if (row < n_wrows) src = F8 ? reinterpret_cast<const T*>(Wg8 + (int64_t)row * K16 + v * 16) : Wg + (int64_t)row * K + v * 8;
-          else {
-            int p = row - n_wrows;
-            if (a.has_expand) { const int ri = fast_div_u(p, wi_rcp); p = (r0 + ri) * PW + q0 + (p - ri * wi); }
-            const int gy = iy0 + p / PW, gx = ix0 + p % PW;
-            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) src = reinterpret_cast<const T*>(a.in) + img + ((int64_t)gy * a.W + gx) * K + cbase + v * 8;
-          }
-          if (src) { x0[j] = *reinterpret_cast<const raw_t*>(src); if (!BF16) x1[j] = *reinterpret_cast<const raw_t*>(src + 4); }
+        for (int j = 0; j < NH; j++, off += wstep) {
+          const unsigned char* src = w_b + (vok_w && base + j * rstride + row0 < n_wrows ? off : 0u);
+          w0[j] = *reinterpret_cast<const raw_t*>(src); if (!BF16) w1[j] = *reinterpret_cast<const raw_t*>(src + 16);
         }
-      }
-      if (base == 0) park_weights();          // their loads were issued first: this waits for them only
+      };
+      auto store_w = [&](int base) {
 #pragma unroll
-      for (int j = 0; j < NB; j++) {
-        const int row = base + j * rstride + row0;
-        if (v < (row < n_wrows ? vecs_w : vecs) && row < n_rows) {
-          raw_t* d = row < n_wrows ? (F8 ? reinterpret_cast<raw_t*>(w8_s + (int64_t)row * KP8 + v * 16) : reinterpret_cast<raw_t*>(w_s + (int64_t)row * KP + v * 8))
-                                   : reinterpret_cast<raw_t*>(dst + (int64_t)(row - n_wrows) * pitch + v * 8);
-          d[0] = x0[j]; if (!BF16) d[1] = x1[j];
+        for (int j = 0; j < NH; j++) {
+          const int row = base + j * rstride + row0;
+          if (vok_w && row < n_wrows) {
+            raw_t* d = F8 ? reinterpret_cast<raw_t*>(w8_s + row * KP8 + v * 16) : reinterpret_cast<raw_t*>(w_s + row * KP + v * 8);
+            d[0] = w0[j]; if (!BF16) d[1] = w1[j];
+          }
+        }
+      };
+      auto issue_p = [&](int base) {
+#pragma unroll
+        for (int j = 0; j < NH; j++) {
+          const int mm = base + j * rstride + row0, m = min(mm, n_in - 1), ri = row_of(m);
+          const uint32_t off = (uint32_t)((pix0 + ri * a.W + (m - ri * wi)) * K) * (uint32_t)sizeof(T) + (uint32_t)(v * VB);
+          const unsigned char* src = in_b + (vok && mm < n_in ? off : 0u);
+          p0[j] = *reinterpret_cast<const raw_t*>(src); if (!BF16) p1[j] = *reinterpret_cast<const raw_t*>(src + 16);
+        }
+      };
+      auto store_p = [&](int base) {
+#pragma unroll
+        for (int j = 0; j < NH; j++) {
+          const int m = base + j * rstride + row0;
+          if (vok && m < n_in) {
+            raw_t* d = reinterpret_cast<raw_t*>(a_s + m * KP + v * 8);
+            d[0] = p0[j]; if (!BF16) d[1] = p1[j];
+          }
+        }
+      };
+      issue_w(0); issue_p(0);
+      XSTAMP(2); park_weights(); XSTAMP(3);                       // their loads were issued first: this waits for them only
+      store_w(0); store_p(0);
+      for (int base = rstride * NH; base < n_wrows; base += rstride * NH) { issue_w(base); store_w(base); }
+      for (int base = rstride * NH; base < n_in; base += rstride * NH) { issue_p(base); store_p(base); }
+    } else {
+      // depthwise alone: the PIN tile pixels of this block's channels, zero outside the image
+      for (int base = 0; base < PIN; base += rstride * NB) {
+        raw_t x0[NB], x1[NB];
+        bool inside[NB];
+#pragma unroll
+        for (int j = 0; j < NB; j++) {
+          const int p = base + j * rstride + row0, ty = p / PW, gy = iy0 + ty, gx = ix0 + p - ty * PW;
+          inside[j] = p < PIN && v < vecs && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+          const uint32_t off = (uint32_t)((gy * a.W + gx) * K + c0) * (uint32_t)sizeof(T) + (uint32_t)(v * VB);
+          const unsigned char* src = in_b + (inside[j] ? off : 0u);
+          x0[j] = *reinterpret_cast<const raw_t*>(src); if (!BF16) x1[j] = *reinterpret_cast<const raw_t*>(src + 16);
+        }
+        if (base == 0) { XSTAMP(2); park_weights(); XSTAMP(3); }
+#pragma unroll
+        for (int j = 0; j < NB; j++) {
+          const int p = base + j * rstride + row0;
+          if (p < PIN && v < vecs) {
+            raw_t* d = reinterpret_cast<raw_t*>(e_s + p * EP + v * 8);
+            d[0] = inside[j] ? x0[j] : raw_t{}; if (!BF16) d[1] = inside[j] ? x1[j] : raw_t{};
+          }
         }
       }
     }
   }
-  MSTAMP(1);
+  MSTAMP(1); XSTAMP(4);
   __syncthreads();
-  MSTAMP(2);
+  MSTAMP(2); XSTAMP(5);
 
   // ---- phase B: expand 1x1 + bias + swish -> e_s ----
   if (a.has_expand) {
     // a wave takes TWO m-tiles per weight fragment (one LDS weight read feeds two MFMAs) and keeps
     // three k-steps of fragments in flight
     const int mpairs = (n_in + 31) >> 5;                           // pairs of 16-pixel m-tiles over the inside pixels
-    int ntsh = 0; while ((1 << ntsh) < ntiles) ntsh++;             // pp -> (mp, nt): a shift and a mask
+    const int ntsh = ntiles <= 1 ? 0 : 32 - __builtin_clz(ntiles - 1);   // pp -> (mp, nt): a shift and a mask
     for (int pp = wave; pp < (mpairs << ntsh); pp += MBF_WAVES) {
       const int nt = pp & ((1 << ntsh) - 1), mp = pp >> ntsh;
       if (nt >= ntiles) continue;
@@ -232,7 +283,7 @@ __global__ __launch_bounds__(TS == 16 ? 1024 : 512) void mbf_kernel(MbfArgs a) {
           const int m = half ? m1 : m0;
           if (m < n_in) {
             const f32x4 acc = half ? acc1 : acc0;
-            const int ri = fast_div_u(m, wi_rcp), p = (r0 + ri) * PW + q0 + (m - ri * wi);   // tile position of inside pixel m
+            const int ri = row_of(m), p = (r0 + ri) * PW + q0 + (m - ri * wi);   // tile position of inside pixel m
             float v[4];
 #pragma unroll
             for (int q = 0; q < 4; q++) v[q] = swish_t<BF16>(fmaf(acc[q], ws[q], bias[q]));
@@ -254,8 +305,7 @@ __global__ __launch_bounds__(TS == 16 ? 1024 : 512) void mbf_kernel(MbfArgs a) {
   // their partial sums over through LDS (the dead input tile) - the phase is a chain of dependent LDS
   // reads per tap row, so halving the rows per lane shortens it.
   const int cgs = cc >> 3;
-  int cgsh = 0; while ((1 << cgsh) < cgs) cgsh++;
-  const int cgp = 1 << cgsh;
+  const int cgsh = cgs <= 1 ? 0 : 32 - __builtin_clz(cgs - 1), cgp = 1 << cgsh;
   // (TS 16: 128 pixel pairs x 8 channel groups = one item per lane, all tap rows, no hand-over)
   constexpr bool SPLIT = TS == 8;
   constexpr int HALF = SPLIT ? MBF_THREADS / 2 : MBF_THREADS;
@@ -349,8 +399,7 @@ __global__ __launch_bounds__(TS == 16 ? 1024 : 512) void mbf_kernel(MbfArgs a) {
         for (int c = 0; c < 4; c++) { cs[c] += s0[c]; cs[4 + c] += s1[c]; }
       }
     }
-    const int tiles = tiles_x * ((a.Ho + TS - 1) / TS);
-    float* hrow = a.hpart + ((int64_t)b * tiles * chunks + bxl) * a.sqp;
+    float* hrow = a.hpart + ((int64_t)b * gridDim.x + bxl) * a.sqp;         // gridDim.x = tiles * chunks
     for (int j = threadIdx.x >> 3; j < ((a.sq + 63) & ~63); j += MBF_THREADS / 8) {
       float dot = 0.f;
       if (j < a.sq && ch < cc) {
@@ -448,5 +497,7 @@ void launch_mbf(const MbfArgs& a_, hipStream_t s) {
 #endif
   const int tiles = ((a.Wo + a.ts - 1) / a.ts) * ((a.Ho + a.ts - 1) / a.ts), chunks = (a.Cexp + a.CC - 1) / a.CC;
   dim3 grid(tiles * chunks, a.B);
+  a.chunks = chunks; a.tiles_x = (a.Wo + a.ts - 1) / a.ts;
+  a.chunks_rcp = rcp_u32(chunks); a.tiles_x_rcp = rcp_u32(a.tiles_x); a.gx_rcp = rcp_u32(grid.x);
   if (a.bf16) launch_mbf_t<true>(a, grid, s); else launch_mbf_t<false>(a, grid, s);
 }
