@@ -108,6 +108,13 @@ template <> struct Vec8<false> {
 __device__ __forceinline__ void xcd_remap2(int bx, int by, int gx, int gy, int* x, int* y);
 // x / d with rcp = rcp_u32(d) (hep_internal.h): exact for x * d < 2^32
 __device__ __forceinline__ int udiv_rcp(int x, uint32_t rcp) { return rcp ? (int)__umulhi((uint32_t)x, rcp) : x; }
+// x / d for 0 <= x < 2^24 with inv ~ 1 / d (v_rcp_f32): float estimate, one correction step either way
+__device__ __forceinline__ int udiv_f(int x, int d, float inv) {
+  int q = (int)((float)x * inv);
+  const int rem = x - q * d;
+  q += rem >= d ? 1 : 0; q -= rem < 0 ? 1 : 0;
+  return q;
+}
 __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
   int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
   int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;

@@ -19,6 +19,18 @@ int pw_se_variant(const PwArgs& a) {
   return (a.K > 256 || a.sqp / (a.bf16 ? 8 : 4) > 2) ? 2 : 1;
 }
 
+#ifdef HEP_PW_TRACE
+unsigned long long* g_pw_trace_host = nullptr;
+extern "C" int hep_dbg_pw_trace(unsigned long long* host, int max_waves, int enable) {
+  static unsigned long long* buf = nullptr;
+  const size_t cap = (size_t)1 << 20;
+  if (!buf) { if (hipMalloc((void**)&buf, cap * 8) != hipSuccess) return -1; hipMemset(buf, 0, cap * 8); }
+  g_pw_trace_host = enable ? buf : nullptr;
+  if (host) { hipDeviceSynchronize(); hipMemcpy(host, buf, (size_t)max_waves * 64, hipMemcpyDeviceToHost); }
+  return (int)(cap / 8);
+}
+#endif
+
 void launch_pw(const PwArgs& a, hipStream_t s) {
   if (a.fp8) launch_pw_prec<2>(a, s);
   else if (a.bf16) launch_pw_prec<1>(a, s);

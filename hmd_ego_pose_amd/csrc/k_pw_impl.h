@@ -56,9 +56,21 @@ struct Step {
 // (deep K on the small maps), 3 the scale vector was finished by se_finish_kernel (k_dw.hip) and is only copied into LDS
 // (blocks whose K x sq weight matrix is too large to be re-read by every workgroup: phi >= 3).  A template parameter
 // because the rows in flight set the kernel's register count.
+// profiling build (make trace): s_memrealtime (100 MHz) stamps of every wave of the selected launch (HEP_PW_TRACE_SEL="K,N")
+#ifdef HEP_PW_TRACE
+extern unsigned long long* g_pw_trace_host;     // device buffer (k_pw.hip); travels in PwArgs::trace_buf
+#define PSTAMP(i) do { stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define PSTAMP(i)
+#endif
+
 template <int PREC, int MT, int NT, int MODE, int ACT, int SEV>
 __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
   constexpr bool BF16 = PREC != 0, F8 = PREC == 2;
+#ifdef HEP_PW_TRACE
+  unsigned long long stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  PSTAMP(0);
   typedef Vec8<BF16> V;
   typedef typename V::elem T;
   typedef Frag<BF16> F;
@@ -73,46 +85,64 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
 
   // ---- block / wave -> tile assignment ----
   constexpr int TILES_PER_BLOCK_N = MODE == 1 ? 4 * NT : NT;
-  const int chunksN = (a.tilesN + TILES_PER_BLOCK_N - 1) / TILES_PER_BLOCK_N;
+  const int chunksN = a.chunksN;
   const int logical = xcd_remap(blockIdx.x, gridDim.x);     // blocks sharing an A strip stay on one XCD
-  const int mblk = logical / chunksN, nchunk = logical % chunksN;
+  const int mblk = udiv_rcp(logical, a.chunksN_rcp), nchunk = logical - mblk * chunksN;   // (launch_pw_prec made the reciprocal)
   int m0, ntile0, kbeg = 0, kend = K;
   if (MODE == 0) { m0 = (mblk * 4 + wave) * (16 * MT); ntile0 = nchunk * NT; }
   else if (MODE == 1) { m0 = mblk * (16 * MT); ntile0 = nchunk * 4 * NT + wave * NT; }
   else {
     m0 = mblk * (16 * MT); ntile0 = nchunk * NT;
-    const int steps = (K + F::KSTEP - 1) / F::KSTEP, per = (steps + 3) / 4;
+    const int steps = (K + F::KSTEP - 1) / F::KSTEP, per = ((steps + 3) / 4 + 1) & ~1;   // even: slices start on whole load batches
     kbeg = min(K, wave * per * F::KSTEP); kend = min(K, (wave + 1) * per * F::KSTEP);
   }
 
   int mrow[MT]; bool mok[MT];
 #pragma unroll
   for (int i = 0; i < MT; i++) { mrow[i] = m0 + i * 16 + r; mok[i] = mrow[i] < M; }
+  // Fragment loads are UNCONDITIONAL on clamped addresses: a load under a branch makes the compiler wait for every
+  // outstanding load at the next use (vmcnt(0)), which turned the ring below back into one round trip per k-step.
+  // Rows >= M and n-tiles >= tilesN read a valid row and their results are never stored; k beyond the wave's slice
+  // re-reads the slice's last vector and the ACTIVATION fragment is zeroed (finite x 0), so W needs no select.
+  const T* arow[MT];
+#pragma unroll
+  for (int i = 0; i < MT; i++) arow[i] = A + (int64_t)min(mrow[i], M - 1) * K;
+  const unsigned char* wrow[NT];
+#pragma unroll
+  for (int j = 0; j < NT; j++) {
+    const int64_t row = (int64_t)(min(ntile0 + j, a.tilesN - 1) * 16 + r) * K;
+    wrow[j] = F8 ? W8 + row : reinterpret_cast<const unsigned char*>(W + row);
+  }
+  const int klast = max(kend - F::KLANE, 0);
   auto load = [&](Step<PREC, MT, NT>& st, int kk) {
-    const int k = kk + F::KLANE * g;
+    const int k = kk + F::KLANE * g, kc = min(k, klast);
     const bool kok = k < kend;
 #pragma unroll
     for (int i = 0; i < MT; i++) {
-      raw_t v = {};
-      if (kok && mok[i]) v = *reinterpret_cast<const raw_t*>(A + (int64_t)mrow[i] * K + k);
-      st.a[i] = v;
+      const raw_t v = *reinterpret_cast<const raw_t*>(arow[i] + kc);
+      st.a[i] = kok ? v : raw_t{};
     }
 #pragma unroll
     for (int j = 0; j < NT; j++) {
-      if constexpr (F8) {
-        u32x2 v = {};
-        if (kok && ntile0 + j < a.tilesN) v = *reinterpret_cast<const u32x2*>(W8 + (int64_t)((ntile0 + j) * 16 + r) * K + k);
-        st.w[j] = v;
-      } else {
-        raw_t v = {};
-        if (kok && ntile0 + j < a.tilesN) v = *reinterpret_cast<const raw_t*>(W + (int64_t)((ntile0 + j) * 16 + r) * K + k);
-        st.w[j] = v;
-      }
+      if constexpr (F8) st.w[j] = *reinterpret_cast<const u32x2*>(wrow[j] + kc);
+      else st.w[j] = *reinterpret_cast<const raw_t*>(wrow[j] + (size_t)kc * sizeof(T));
     }
   };
-  // the first k-step's fragments do not depend on the squeeze-excite scale: they are in flight during the prologue
-  Step<PREC, MT, NT> cur, nxt;
-  if (kbeg < kend) load(cur, kbeg);
+  // Modes 1 and 2 (small maps) take TWO k-steps per load batch: a lane's fragment is 16 bytes, the four lane groups of a
+  // row cover 64 bytes, so one k-step touches half of a 128-byte line per row and the other half one step later - by
+  // then the workgroup's own traffic (40 KB per step, 32 KB of L1) had evicted the line and every line came from L2
+  // twice.  That doubled traffic, not latency, bounded these GEMMs: a workgroup moves its 100-200 KB at the ~64 GB/s
+  // one CU gets out of L2, and a deeper ring changed nothing.  With both halves requested back to back the second one
+  // merges with the miss in flight.  One batch stays in flight behind the one being multiplied (two slots); the first
+  // does not depend on the squeeze-excite scale and is issued before its prologue.
+  constexpr int U = MODE == 0 ? 1 : 2, KS2 = U * F::KSTEP;
+  Step<PREC, MT, NT> st[2][U];
+  auto load2 = [&](int slot, int kk) {
+#pragma unroll
+    for (int u = 0; u < U; u++) load(st[slot][u], kk + u * F::KSTEP);
+  };
+  load2(0, kbeg);
+  PSTAMP(1);
 
   // ---- squeeze-excite prologue: scale_s[image - img0][k] for the images this workgroup's rows belong to ----
   // A chain of dependent round trips if written naively (hpart rows -> hidden -> weight rows -> scale), and it
@@ -122,22 +152,30 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
   // dtype (bf16 sessions: half the bytes; the products are accumulated in fp32).
   extern __shared__ __attribute__((aligned(16))) float se_s[];
   constexpr bool SE = SEV != 0;
+  const float hw_inv = SE ? __builtin_amdgcn_rcpf((float)a.HW) : 0.f;
   int img0 = 0;
   if constexpr (SEV == 3) {
     constexpr int ROWS = MODE == 0 ? 64 * MT : 16 * MT;
     const int mfirst = mblk * ROWS, mlast = min(M, mfirst + ROWS) - 1;
-    img0 = mfirst / a.HW;
-    const int nimg = mlast / a.HW - img0 + 1;
-    for (int i = threadIdx.x * 4; i < nimg * K; i += 256 * 4)          // K is a multiple of 8
-      *reinterpret_cast<f32x4*>(se_s + i) = *reinterpret_cast<const f32x4*>(a.se_scale + (int64_t)img0 * K + i);
+    img0 = udiv_f(mfirst, a.HW, hw_inv);
+    const int nimg = udiv_f(mlast, a.HW, hw_inv) - img0 + 1;
+    const float* sc_g = a.se_scale + (int64_t)img0 * K;
+    const int nsc = nimg * K;                                             // K is a multiple of 8
+    for (int i0 = threadIdx.x * 4; i0 < nsc; i0 += 256 * 4 * 4) {         // four vectors in flight per lane: K <= 4096 is one round trip
+      f32x4 v[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) v[q] = *reinterpret_cast<const f32x4*>(sc_g + min(i0 + q * 1024, nsc - 4));
+#pragma unroll
+      for (int q = 0; q < 4; q++) if (i0 + q * 1024 < nsc) *reinterpret_cast<f32x4*>(se_s + i0 + q * 1024) = v[q];
+    }
     __syncthreads();
   } else if constexpr (SE) {
     constexpr int ROWS = MODE == 0 ? 64 * MT : 16 * MT;
     constexpr int JV = BF16 ? 8 : 4;              // hidden units per 16-byte weight vector
     constexpr int RB = SEV == 2 ? 5 : 1, VB = SEV == 2 ? 6 : 2;   // weight rows x vectors in flight per lane
     const int mfirst = mblk * ROWS, mlast = min(M, mfirst + ROWS) - 1;
-    img0 = mfirst / a.HW;
-    const int img1 = mlast / a.HW, sqp = a.sqp, sq = a.sq;
+    img0 = udiv_f(mfirst, a.HW, hw_inv);
+    const int img1 = udiv_f(mlast, a.HW, hw_inv), sqp = a.sqp, sq = a.sq;
     const int V = sqp / JV, R = (K + 255) >> 8;
     const T* WE = reinterpret_cast<const T*>(a.se_we);
     float* hid_s = se_s + a.se_nimg * K;          // [sqp]
@@ -221,9 +259,27 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
     }
   }
 
+  PSTAMP(2);
   int mimg[MT];
 #pragma unroll
-  for (int i = 0; i < MT; i++) mimg[i] = (SE && mok[i]) ? mrow[i] / a.HW - img0 : 0;
+  for (int i = 0; i < MT; i++) mimg[i] = (SE && mok[i]) ? udiv_f(mrow[i], a.HW, hw_inv) - img0 : 0;
+  // split-K workgroups are the latency chains: their bias and residual are fetched here, under the K loop
+  const T* R = reinterpret_cast<const T*>(a.res);
+  constexpr bool HOIST = MODE == 2;
+  // (unconditional on clamped addresses, raw: converted in the epilogue; wave w owns n-tiles j = w and w + 4)
+  typedef typename std::conditional<BF16, u32x2, f32x4>::type res_t;
+  constexpr int NH = HOIST ? (NT + 3) / 4 : 1;
+  f32x4 bias_h[NH]; res_t res_h[HOIST ? MT : 1][NH];
+  if constexpr (HOIST) {
+#pragma unroll
+    for (int jj = 0; jj < NH; jj++) {
+      const int n = min((ntile0 + wave + 4 * jj) * 16 + 4 * g, a.N - 4);                 // N is a multiple of 8
+      bias_h[jj] = *reinterpret_cast<const f32x4*>(a.bias + n);
+#pragma unroll
+      for (int i = 0; i < MT; i++)
+        res_h[i][jj] = *reinterpret_cast<const res_t*>((R ? R : A) + (R ? (int64_t)min(mrow[i], M - 1) * a.N + n : 0));
+    }
+  }
   f32x4 acc[MT][NT];
 #pragma unroll
   for (int i = 0; i < MT; i++)
@@ -285,16 +341,21 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
     }
   };
 
-  if (kbeg < kend) {
-    int kk = kbeg;
-    for (; kk + F::KSTEP < kend; kk += F::KSTEP) {
-      load(nxt, kk + F::KSTEP);
-      compute(cur, kk);
-      cur = nxt;
-    }
-    compute(cur, kk);
+  auto compute2 = [&](int slot, int kk) {
+#pragma unroll
+    for (int u = 0; u < U; u++) if (u == 0 || kk + u * F::KSTEP < kend) compute(st[slot][u], kk + u * F::KSTEP);   // (wave-uniform)
+  };
+  // steady state: both following batches exist, no condition anywhere near a load; the last one or two batches are
+  // peeled so that no load is issued past the slice (a single-batch GEMM - K <= 32 on the big maps - loads once)
+  int kk = kbeg;
+  for (; kk + 2 * KS2 < kend; kk += 2 * KS2) {
+    load2(1, kk + KS2); compute2(0, kk);
+    load2(0, kk + 2 * KS2); compute2(1, kk + KS2);
   }
+  if (kk + KS2 < kend) { load2(1, kk + KS2); compute2(0, kk); compute2(1, kk + KS2); }
+  else if (kk < kend) compute2(0, kk);
 
+  PSTAMP(3);
   if (MODE == 2) {   // meet the four K-slices in LDS; wave w finishes n-tiles j = w, w+4, ...
     __shared__ f32x4 red[4][MT][NT][64];
 #pragma unroll
@@ -309,14 +370,15 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
         if ((j & 3) == wave) acc[i][j] = (red[0][i][j][lane] + red[1][i][j][lane]) + (red[2][i][j][lane] + red[3][i][j][lane]);
   }
 
+  PSTAMP(4);
   // ---- epilogue: lane holds n = nt*16 + 4g + {0..3} for pixel row m0 + 16 i + r ----
-  const T* R = reinterpret_cast<const T*>(a.res);
 #pragma unroll
   for (int j = 0; j < NT; j++) {
     if (MODE == 2 && (j & 3) != wave) continue;
     const int n = (ntile0 + j) * 16 + 4 * g;
     if (n >= a.N) continue;
-    const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias + n);
+    f32x4 b;
+    if constexpr (HOIST) b = bias_h[j >> 2]; else b = *reinterpret_cast<const f32x4*>(a.bias + n);
     f32x4 ws = (f32x4){1.f, 1.f, 1.f, 1.f};
     if constexpr (F8) ws = *reinterpret_cast<const f32x4*>(a.wscale + n) * a.a_scale;     // dequantisation: a_scale * w_scale[n]
 #pragma unroll
@@ -327,13 +389,25 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
       for (int q = 0; q < 4; q++) { const float x = F8 ? fmaf(acc[i][j][q], ws[q], b[q]) : acc[i][j][q] + b[q]; v[q] = ACT == ACT_SWISH ? swish_t<BF16>(x) : x; }
       const int64_t o = (int64_t)mrow[i] * a.N + n;
       if (R) {
-        float rr[4]; V::load4(R, o, rr);
+        float rr[4];
+        if constexpr (HOIST) {
+          const res_t rv = res_h[i][j >> 2];
+          if constexpr (BF16) { rr[0] = __uint_as_float(rv[0] << 16); rr[1] = __uint_as_float(rv[0] & 0xffff0000u); rr[2] = __uint_as_float(rv[1] << 16); rr[3] = __uint_as_float(rv[1] & 0xffff0000u); }
+          else { rr[0] = rv[0]; rr[1] = rv[1]; rr[2] = rv[2]; rr[3] = rv[3]; }
+        } else V::load4(R, o, rr);
 #pragma unroll
         for (int q = 0; q < 4; q++) v[q] += rr[q];
       }
       V::store4(a.out, o, v);
     }
   }
+#ifdef HEP_PW_TRACE
+  PSTAMP(5);
+  if (a.trace_buf && lane == 0) {
+    unsigned long long* o = a.trace_buf + ((size_t)blockIdx.x * 4 + wave) * 8;
+    for (int i = 0; i < 6; i++) o[i] = stamps[i];
+  }
+#endif
 }
 
 template <int PREC, int MT, int MODE>
@@ -355,11 +429,15 @@ static void launch_nt(const PwArgs& a, dim3 grid, hipStream_t s) {
 // one translation unit per precision (k_pw_f32.hip, k_pw_bf16.hip, k_pw_fp8.hip) instantiates this: the three sets of
 // ~190 kernels compile in parallel
 template <int PREC>
-void launch_pw_prec(const PwArgs& a, hipStream_t s) {
-  const int per_block_n = a.mode == 1 ? 4 * a.NT : a.NT;
-  const int chunksN = (a.tilesN + per_block_n - 1) / per_block_n;
-  const int rows = a.mode == 0 ? 64 * a.MT : 16 * a.MT;
-  dim3 grid(((a.M + rows - 1) / rows) * chunksN);
+void launch_pw_prec(const PwArgs& a_, hipStream_t s) {
+  const int per_block_n = a_.mode == 1 ? 4 * a_.NT : a_.NT;
+  const int chunksN = (a_.tilesN + per_block_n - 1) / per_block_n;
+  const int rows = a_.mode == 0 ? 64 * a_.MT : 16 * a_.MT;
+  dim3 grid(((a_.M + rows - 1) / rows) * chunksN);
+  PwArgs a = a_; a.chunksN = chunksN; a.chunksN_rcp = rcp_u32(chunksN);
+#ifdef HEP_PW_TRACE
+  { static const char* sel = getenv("HEP_PW_TRACE_SEL"); int k = 0, n = 0; if (sel) sscanf(sel, "%d,%d", &k, &n); a.trace_buf = sel && a.K == k && a.N == n ? g_pw_trace_host : nullptr; }
+#endif
   if (a.mode == 0) { if (a.MT == 2) launch_nt<PREC, 2, 0>(a, grid, s); else launch_nt<PREC, 1, 0>(a, grid, s); }
   else if (a.mode == 1) { if (a.MT == 2) launch_nt<PREC, 2, 1>(a, grid, s); else launch_nt<PREC, 1, 1>(a, grid, s); }
   else { if (a.MT == 2) launch_nt<PREC, 2, 2>(a, grid, s); else launch_nt<PREC, 1, 2>(a, grid, s); }
