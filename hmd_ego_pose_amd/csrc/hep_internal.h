@@ -110,6 +110,7 @@ struct SepSeg {
   int n_base;                              // first output column of this segment (wide headers are split)
   int ts;                                  // tile side: 16 on maps >= 16x16 (bf16), else 8
   int tiles_x, tiles_y, tile_begin;        // tile_begin = prefix of tiles-per-image over the launch's segments
+  uint32_t tiles_x_rcp;                    // rcp_u32(tiles_x)
 };
 struct SepArgs {
   const SepSeg* segs; const int* tile_seg;   // device tables: segments, and tile (blockIdx.x) -> segment

@@ -633,7 +633,7 @@ struct Planner {
         sg.ts = ts_pick;   // 8; 16x16 tiles measured slower (3 dependent gather rounds per lane, 1 workgroup per CU)
         ts_max = std::max(ts_max, sg.ts);
         if (sp.out_t >= 0) cols_map = std::max(cols_map, Nc); else cols_f32 = std::max(cols_f32, Nc);
-        sg.tiles_x = (hw + sg.ts - 1) / sg.ts; sg.tiles_y = sg.tiles_x; sg.tile_begin = tile_begin;
+        sg.tiles_x = (hw + sg.ts - 1) / sg.ts; sg.tiles_y = sg.tiles_x; sg.tile_begin = tile_begin; sg.tiles_x_rcp = rcp_u32(sg.tiles_x);
         tile_begin += sg.tiles_x * sg.tiles_y;
         if (sp.out_t >= 0) {
           sg.out_f32 = 0; sg.out_bstride = (int64_t)hw * hw * sp.N; sg.out_off = n0; sg.out_rowstride = sp.N;

@@ -62,41 +62,45 @@ template <> struct Raw8<false> {
 // fused value of 8 channels at (y, x): sum_i fw_i * gather_i, optional swish.  Every load of the
 // item is issued before the first one is consumed (one memory round trip per item in bf16; the
 // fp32 parity mode walks the max-pool window row by row to stay inside the register budget).
+// All loads are UNCONDITIONAL on in-range addresses (a load under a branch costs its own round trip): SAME and UP
+// sources differ by a shift, a DOWN source is also read at (y, x) (in range: it is the larger map) and ignored,
+// window taps outside the map read a clamped address and are replaced by the zero padding.  Offsets inside an image
+// are 32-bit; the per-image base is uniform.
 template <bool BF16>
 __device__ __forceinline__ void gather_fuse(const SepSeg& sg, int b, int y, int x, int c0, float v[8]) {
   const int C = sg.C;
   constexpr int ROWS = BF16 ? 3 : 1;        // window rows in flight at once
+  typedef typename std::conditional<BF16, bf16_t, float>::type T;
   Raw8<BF16> same[HEP_MAX_SRC];
   Raw8<BF16> win[ROWS * 3];
   // (the descriptor's arrays are only ever indexed by unrolled constants: a run-time index would
   //  push the whole by-value struct out of scalar registers into scratch memory)
-  int down = -1, dsh = 0, dsw = 0, dpad = 0; const void* dsrc = nullptr;
+  int down = -1, dsh = 1, dsw = 1, dpad = 0; const T* dsrc = reinterpret_cast<const T*>(sg.src[0]);
 #pragma unroll
   for (int i = 0; i < HEP_MAX_SRC; i++) {
-    if (i >= sg.nsrc) break;
-    const int sh = sg.sh[i], sw = sg.sw[i];
-    const int64_t img = (int64_t)b * sh * sw * C;
-    if (sg.kind[i] == SRC_SAME) same[i].load(sg.src[i], img + ((int64_t)y * sw + x) * C + c0);
-    else if (sg.kind[i] == SRC_UP) same[i].load(sg.src[i], img + ((int64_t)(y >> 1) * sw + (x >> 1)) * C + c0);
-    else { down = i; dsh = sh; dsw = sw; dpad = sg.pool_pad[i]; dsrc = sg.src[i]; }   // SRC_DOWN (at most one per node)
+    const bool used = i < sg.nsrc;                                   // (uniform)
+    const int sh = used ? sg.sh[i] : sg.sh[0], sw = used ? sg.sw[i] : sg.sw[0];
+    const T* src = reinterpret_cast<const T*>(used ? sg.src[i] : sg.src[0]) + (int64_t)b * sh * sw * C;
+    const int kind = used ? sg.kind[i] : SRC_SAME, sft = kind == SRC_UP ? 1 : 0;
+    same[i].load(src, (uint32_t)(((y >> sft) * sw + (x >> sft)) * C + c0));
+    if (used && kind == SRC_DOWN) { down = i; dsh = sh; dsw = sw; dpad = sg.pool_pad[i]; dsrc = src; }   // (at most one per node)
   }
   float pooled[8];
-  if (down >= 0) {
-    const int sh = dsh, sw = dsw;
-    const int64_t img = (int64_t)b * sh * sw * C;
+  if (down >= 0) {                                                  // (uniform)
 #pragma unroll
     for (int r0 = 0; r0 < 3; r0 += ROWS) {
+      bool in[ROWS * 3];
 #pragma unroll
       for (int q = 0; q < ROWS * 3; q++) {
         const int iy = 2 * y - dpad + r0 + q / 3, ix = 2 * x - dpad + q % 3;
-        win[q].zero();
-        if (iy >= 0 && iy < sh && ix >= 0 && ix < sw) win[q].load(dsrc, img + ((int64_t)iy * sw + ix) * C + c0);
+        in[q] = iy >= 0 && iy < dsh && ix >= 0 && ix < dsw;
+        win[q].load(dsrc, (uint32_t)((min(max(iy, 0), dsh - 1) * dsw + min(max(ix, 0), dsw - 1)) * C + c0));
       }
 #pragma unroll
       for (int c = 0; c < 8; c++) {
-        float m = win[0].get(c);
+        float m = in[0] ? win[0].get(c) : 0.f;
 #pragma unroll
-        for (int q = 1; q < ROWS * 3; q++) m = fmaxf(m, win[q].get(c));
+        for (int q = 1; q < ROWS * 3; q++) m = fmaxf(m, in[q] ? win[q].get(c) : 0.f);
         pooled[c] = r0 == 0 ? m : fmaxf(pooled[c], m);
       }
     }
@@ -139,7 +143,8 @@ __global__ __launch_bounds__(SEP_THREADS_OF(MODE), MODE == 1 ? SEP_M1_WAVES : 4)
   const int C = sg.C, CG = C >> 3, h = sg.h, w = sg.w, TS = sg.ts, HS = TS + 2;
   const int t = MODE == 2 ? 0 : blockIdx.x - sg.tile_begin;
   const int b = blockIdx.y;                 // grid = (tiles of one image over all segments, batch)
-  const int y0 = (t / sg.tiles_x) * TS, x0 = (t % sg.tiles_x) * TS;
+  const int tile_y = udiv_rcp(t, sg.tiles_x_rcp);
+  const int y0 = tile_y * TS, x0 = (t - tile_y * sg.tiles_x) * TS;
   const int CH = C + PAD;                   // halo and operand-tile row pitch (elements)
   T* halo = reinterpret_cast<T*>(smem);
   T* atile = reinterpret_cast<T*>(smem + a.off_atile);
@@ -155,11 +160,32 @@ __global__ __launch_bounds__(SEP_THREADS_OF(MODE), MODE == 1 ? SEP_M1_WAVES : 4)
   const int mtv = TS == 16 ? rows_valid : (TS == 8 ? (rows_valid + 1) >> 1 : 1);   // 16-pixel m-tiles holding a valid pixel (TS 4: the whole tile)
   const int ksteps = (C + KSTEP - 1) / KSTEP;
   const T* W = reinterpret_cast<const T*>(sg.wpw);
-  int cgsh = 0; while ((1 << cgsh) < CG) cgsh++;
+  const int cgsh = CG <= 1 ? 0 : 32 - __builtin_clz(CG - 1);
   const int tssh = TS == 16 ? 4 : (TS == 8 ? 3 : 2);
-  // ---- phase 0: depthwise weights + bias to LDS (independent of the activations) ----
-  for (int i = threadIdx.x; i < 9 * C; i += SEP_THREADS) wdw_s[i] = sg.wdw[i];
-  for (int i = threadIdx.x; i < sg.tilesN * 16; i += SEP_THREADS) bias_s[i] = sg.bias[i];
+  const int mtsh = mtv <= 1 ? 0 : 32 - __builtin_clz(mtv - 1);
+  // ---- phase 0: everything that does not depend on the activations is REQUESTED here and parked in LDS once the
+  //      gathers are in flight: depthwise weights, bias (16-byte vectors; were two dword loops = two round trips in
+  //      front of the gathers) and the weight fragments of this wave's first (m-tile, n-tile) pair of phase 3 (were
+  //      a global round trip between the depthwise conv and the MFMAs) ----
+  const int nwv = (9 * C) >> 2, nbv = sg.tilesN * 4;
+  const f32x4* wdw_g = reinterpret_cast<const f32x4*>(sg.wdw);
+  const f32x4 wv0 = wdw_g[min((int)threadIdx.x, nwv - 1)];
+  const f32x4 bv = reinterpret_cast<const f32x4*>(sg.bias)[min((int)threadIdx.x, nbv - 1)];
+  constexpr int WPRE = 2;                                 // k-steps of prefetched weight fragments (all of them for C = 64 in bf16)
+  raw_t wpre[WPRE];
+  {
+    const T* wrow = W + (int64_t)(min(wave >> mtsh, sg.tilesN - 1) * 16 + r) * C;
+#pragma unroll
+    for (int q = 0; q < WPRE; q++) {
+      wpre[q] = *reinterpret_cast<const raw_t*>(wrow + min(q * KSTEP + KLANE * g, C - KLANE));   // (k >= C meets a zero activation fragment)
+    }
+  }
+  auto park = [&]() {
+    f32x4* wd = reinterpret_cast<f32x4*>(wdw_s);
+    if ((int)threadIdx.x < nwv) wd[threadIdx.x] = wv0;
+    for (int i = threadIdx.x + SEP_THREADS; i < nwv; i += SEP_THREADS) wd[i] = wdw_g[i];      // (C > 455 / 227 only)
+    if ((int)threadIdx.x < nbv) reinterpret_cast<f32x4*>(bias_s)[threadIdx.x] = bv;
+  };
 
   // ---- phase 1: fused (+swish) halo of the depthwise input, zero outside the image ----
   {
@@ -173,6 +199,7 @@ __global__ __launch_bounds__(SEP_THREADS_OF(MODE), MODE == 1 ? SEP_M1_WAVES : 4)
         V::store(halo, (int64_t)pos * CH + cg * 8, v);
       }
   }
+  park();
   __syncthreads();
 
   // ---- phase 2: depthwise 3x3 -> operand tile [TS*TS pixels][C] ----
@@ -203,7 +230,6 @@ __global__ __launch_bounds__(SEP_THREADS_OF(MODE), MODE == 1 ? SEP_M1_WAVES : 4)
   float* otile_f = reinterpret_cast<float*>(smem);        // [TS*TS][Nc] fp32 (head outputs)
   T* otile_t = reinterpret_cast<T*>(smem);                // [TS*TS][Nc] dtype (maps)
   // (m-tile, n-tile) pairs are dealt round-robin to the waves; pair -> (nt, mt) is a shift and a mask
-  int mtsh = 0; while ((1 << mtsh) < mtv) mtsh++;
   for (int pair = wave; pair < (sg.tilesN << mtsh); pair += SEP_WAVES) {
     const int nt = pair >> mtsh, mt = pair & ((1 << mtsh) - 1);
     if (mt >= mtv) continue;
@@ -211,15 +237,22 @@ __global__ __launch_bounds__(SEP_THREADS_OF(MODE), MODE == 1 ? SEP_M1_WAVES : 4)
     const T* wrow = W + (int64_t)(nt * 16 + r) * C + KLANE * g;
     const T* arow = atile + (int64_t)m * CH + KLANE * g;
     f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-    for (int ks = 0; ks < ksteps; ks++) {
-      raw_t wf = {}, xa = {};
-      if (ks * KSTEP + KLANE * g < C) { wf = *reinterpret_cast<const raw_t*>(wrow + ks * KSTEP); xa = *reinterpret_cast<const raw_t*>(arow + ks * KSTEP); }
-      if constexpr (BF16) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf), __builtin_bit_cast(bf16x8, xa), acc, 0, 0, 0);
-      } else {
+    for (int ks0 = 0; ks0 < ksteps; ks0 += WPRE) {        // (a trailing partial group multiplies zeros)
 #pragma unroll
-        for (int q = 0; q < 4; q++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[q], xa[q], acc, 0, 0, 0);
+      for (int q = 0; q < WPRE; q++) {
+        const int ks = ks0 + q;
+        raw_t wf = {}, xa = {};
+        if (ks * KSTEP + KLANE * g < C) {
+          xa = *reinterpret_cast<const raw_t*>(arow + ks * KSTEP);
+          if (pair == wave && ks0 == 0) wf = wpre[q];       // (uniform) requested at kernel start
+          else wf = *reinterpret_cast<const raw_t*>(wrow + ks * KSTEP);
+        }
+        if constexpr (BF16) {
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf), __builtin_bit_cast(bf16x8, xa), acc, 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int qq = 0; qq < 4; qq++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[qq], xa[qq], acc, 0, 0, 0);
+        }
       }
     }
     const int n = nt * 16 + 4 * g;          // lane: 4 consecutive columns of pixel m
@@ -257,7 +290,7 @@ __global__ __launch_bounds__(SEP_THREADS_OF(MODE), MODE == 1 ? SEP_M1_WAVES : 4)
     // write consecutive 16-byte vectors of a pixel, then the next pixel of the tile row
     T* o = reinterpret_cast<T*>(sg.out) + (int64_t)b * sg.out_bstride + sg.out_off;
     const int vpp = Nc >> 3;
-    int vsh = 0; while ((1 << vsh) < vpp) vsh++;
+    const int vsh = vpp <= 1 ? 0 : 32 - __builtin_clz(vpp - 1);
     const int cv = threadIdx.x & ((1 << vsh) - 1);
     if (cv < vpp)
       for (int pix = threadIdx.x >> vsh; pix < TS * TS; pix += SEP_THREADS >> vsh) {
