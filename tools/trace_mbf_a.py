@@ -1,3 +1,4 @@
+# phase-A sub-steps of mbf_kernel (profiling build: make -C hmd_ego_pose_amd/csrc trace_a); usage as tools/trace_mbf.py
 import sys, ctypes; import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from hmd_ego_pose_amd import _capi
