@@ -41,6 +41,7 @@ SYMBOLS = {
     "hep_pose_errors": (c_int, [c_int, _FP, c_int, _FP, _FP, _FP, _FP, c_int, c_int, _FP, _FP]),
     "hep_pose_errors_device": (c_int, [_FP, c_int, _FP, _FP, _FP, _FP, c_int, c_int, _FP, _FP, c_void_p]),
     "hep_anchor_targets_device": (c_int, [_FP, c_int, _FP, _FP, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_double, c_double, _FP, _FP, _FP, _FP, c_void_p]),
+    "hep_losses_device": (c_int, [_FP] * 9 + [c_int] * 7 + [_FP, _FP, c_void_p]),
     "hep_debug_tensor_count": (c_int, [_P]),
     "hep_debug_tensor_info": (c_int, [_P, c_int, POINTER(c_char_p), POINTER(c_int64)]),
     "hep_debug_tensor": (c_int, [_P, c_char_p, c_int, _FP, c_size_t]),

@@ -532,6 +532,23 @@ int hep_anchor_targets_device(const float* anchors, int num_anchors, const doubl
   return 0;
 }
 
+int hep_losses_device(const float* gt_classification, const float* classification, const float* gt_regression, const float* regression,
+                      const float* gt_transformation, const float* transformation, const float* gt_hand, const float* hand,
+                      const float* model_points, int batch, int num_anchors, int num_classes, int num_rotation, int num_hand,
+                      int num_model_classes, int num_points, float* per_image, float* losses, void* stream) {
+  if (!gt_classification || !classification || !gt_regression || !regression || !gt_transformation || !transformation || !model_points ||
+      !per_image || !losses) return fail(HEP_ERR_INVALID, "bad argument");
+  if ((gt_hand == nullptr) != (hand == nullptr)) return fail(HEP_ERR_INVALID, "gt_hand and hand go together");
+  if (batch < 1 || num_anchors < 1 || num_classes < 1 || num_rotation != 3 || num_hand < 0 || num_model_classes < 1) return fail(HEP_ERR_INVALID, "bad size");
+  if (num_points < 1 || num_points > LOSS_MAX_POINTS) return fail(HEP_ERR_UNSUPPORTED, "num_points must be in 1..2048 model points per class");
+  LossArgs a; a.gt_cls = gt_classification; a.cls = classification; a.gt_reg = gt_regression; a.reg = regression; a.gt_tr = gt_transformation;
+  a.tr = transformation; a.gt_hand = gt_hand; a.hand = hand; a.points = model_points; a.B = batch; a.N = num_anchors; a.K = num_classes;
+  a.R = num_rotation; a.H = num_hand; a.classes = num_model_classes; a.P = num_points; a.per_image = per_image; a.losses = losses;
+  launch_losses(a, (hipStream_t)stream);
+  HIPRET(hipGetLastError());
+  return 0;
+}
+
 // ---- introspection ----
 int hep_debug_tensor_count(const hep_handle* h) { return h ? (int)h->s.tensors.size() : 0; }
 int hep_debug_tensor_info(const hep_handle* h, int i, const char** name, int64_t dims[4]) {

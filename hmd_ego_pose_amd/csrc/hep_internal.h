@@ -187,6 +187,20 @@ struct AnchorTargetArgs {
 };
 void launch_anchor_targets(const AnchorTargetArgs&, hipStream_t);
 
+// ---- training side: the five losses of batch_iterate (hmdegopose/loss.py:54-99), forward values ----
+#define LOSS_MAX_POINTS 2048
+struct LossArgs {
+  const float* gt_cls; const float* cls;        // [B][N][K+1] (labels, anchor state) ; [B][N][K] scores
+  const float* gt_reg; const float* reg;        // [B][N][5] ; [B][N][4]
+  const float* gt_tr; const float* tr;          // [B][N][R+3+3] (rotation, translation, is_symmetric, class, state) ; [B][N][R+3]
+  const float* gt_hand; const float* hand;      // [B][N][H+1] ; [B][N][H] (both nullable: hand loss 0)
+  const float* points;                          // [classes][P][3]
+  int B, N, K, R, H, classes, P;
+  float* per_image;                             // [B][5]: classification, regression, rotation, translation, hand
+  float* losses;                                // [5]: batch means, regression x 50
+};
+void launch_losses(const LossArgs&, hipStream_t);
+
 void launch_stem(const StemArgs&, hipStream_t);
 void launch_pw(const PwArgs&, hipStream_t);
 int pw_se_variant(const PwArgs&);   // 0 none, 1 shallow, 2 deep (template parameter of pw_gemm_kernel)

@@ -177,3 +177,185 @@ __global__ __launch_bounds__(AT_THREADS) void anchor_targets_kernel(AnchorTarget
 void launch_anchor_targets(const AnchorTargetArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(anchor_targets_kernel, dim3(a.B), dim3(AT_THREADS), 0, s, a);
 }
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// Training side: forward values of the five losses of `batch_iterate` (reference hmdegopose/loss.py:54-99):
+//   classification  focal(alpha 0.25, gamma 1.5) over the non-ignored anchors / max(1, #object anchors)    (102-167)
+//   regression      smooth-L1 (sigma 3, `<=` at the knee) over the object anchors / max(1, #)             (170-219)
+//   rotation        mean over the object anchors of the mean point distance between the model rotated by the
+//                   predicted and by the target axis-angle (x pi): nearest target point when the object is
+//                   symmetric; NaN -> 0                                                                    (273-428)
+//   translation     torch SmoothL1Loss (beta 1, mean) over the object anchors x 3: NaN without any, as the
+//                   reference returns it
+//   hand            smooth-L1 (sigma 3) over the object anchors / max(1, #)                                (222-271)
+// One workgroup per image (the reference loops over the batch, 54-99); float32 like torch, no contraction; every sum
+// is reduced in a fixed order (lane-strided partial sums, then a tree): bit-reproducible.  The object anchors are
+// compacted in anchor order with a block scan and their point clouds are rotated one anchor at a time by the
+// whole workgroup, the target cloud in LDS.  A second tiny launch averages over the batch (regression x 50).
+// ------------------------------------------------------------------------------------------------------------------
+#define LOSS_THREADS 1024
+#define LOSS_LIST 2048
+
+__device__ __forceinline__ float smooth_l1_sigma3(float d) {
+#pragma clang fp contract(off)
+  const float s2 = 9.0f;
+  d = fabsf(d);
+  return d <= 1.0f / s2 ? 0.5f * s2 * (d * d) : d - 0.5f / s2;
+}
+
+// block-wide sum in a fixed order; every thread gets the result
+__device__ float block_sum(float v, float* red) {
+#pragma clang fp contract(off)
+  __syncthreads();
+  red[threadIdx.x] = v;
+  __syncthreads();
+  for (int o = LOSS_THREADS / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  return red[0];
+}
+
+struct AxisAngle { float ax, ay, az, c, s; };
+__device__ __forceinline__ AxisAngle axis_angle(const float* r) {
+#pragma clang fp contract(off)
+  const float pi = 3.14159265358979323846f;
+  const float x = r[0] * pi, y = r[1] * pi, z = r[2] * pi;
+  const float angle = sqrtf((x * x + y * y) + z * z);
+  AxisAngle q; q.ax = x / angle; q.ay = y / angle; q.az = z / angle; q.c = cosf(angle); q.s = sinf(angle);
+  return q;
+}
+// point * cos + cross(axis, point) * sin + axis * dot(axis, point) * (1 - cos)      (loss.py:570-609)
+__device__ __forceinline__ void rotate_pt(const AxisAngle& q, const float* p, float o[3]) {
+#pragma clang fp contract(off)
+  const float dt = (q.ax * p[0] + q.ay * p[1]) + q.az * p[2], omc = 1.0f - q.c;
+  const float cx = q.ay * p[2] - q.az * p[1], cy = q.az * p[0] - q.ax * p[2], cz = q.ax * p[1] - q.ay * p[0];
+  o[0] = (p[0] * q.c + cx * q.s) + (q.ax * dt) * omc;
+  o[1] = (p[1] * q.c + cy * q.s) + (q.ay * dt) * omc;
+  o[2] = (p[2] * q.c + cz * q.s) + (q.az * dt) * omc;
+}
+
+__global__ __launch_bounds__(LOSS_THREADS) void losses_kernel(LossArgs a) {
+#pragma clang fp contract(off)
+  __shared__ float red[LOSS_THREADS];
+  __shared__ int scan[LOSS_THREADS];
+  __shared__ int list[LOSS_LIST];
+  __shared__ float tgt[LOSS_MAX_POINTS * 3];
+  const int b = blockIdx.x, t = threadIdx.x, N = a.N, K = a.K, R = a.R, H = a.H;
+  const float* gc = a.gt_cls + (int64_t)b * N * (K + 1); const float* pc = a.cls + (int64_t)b * N * K;
+  const float* gr = a.gt_reg + (int64_t)b * N * 5;       const float* pr = a.reg + (int64_t)b * N * 4;
+  const float* gt = a.gt_tr + (int64_t)b * N * (R + 6);  const float* pt = a.tr + (int64_t)b * N * (R + 3);
+  const float* gh = a.gt_hand ? a.gt_hand + (int64_t)b * N * (H + 1) : nullptr;
+  const float* ph = a.hand ? a.hand + (int64_t)b * N * H : nullptr;
+
+  // ---- pass 1: the per-anchor sums ----
+  float s_f = 0.f, s_r = 0.f, s_t = 0.f, s_h = 0.f, n_c = 0.f, n_r = 0.f, n_t = 0.f, n_h = 0.f;
+  for (int n = t; n < N; n += LOSS_THREADS) {
+    const float st_c = gc[(int64_t)n * (K + 1) + K];
+    if (st_c == 1.0f) n_c += 1.f;
+    if (st_c != -1.0f)
+      for (int k = 0; k < K; k++) {
+        const float l = gc[(int64_t)n * (K + 1) + k];
+        const float p = fminf(fmaxf(pc[(int64_t)n * K + k], 1e-4f), 1.0f - 1e-4f);
+        const float af = l == 1.0f ? 0.25f : 1.0f - 0.25f;
+        const float fw = af * powf(l == 1.0f ? 1.0f - p : p, 1.5f);
+        const float bce = -(l * logf(p) + (1.0f - l) * logf(1.0f - p));
+        if (l != -1.0f) s_f += fw * bce;
+      }
+    if (gr[(int64_t)n * 5 + 4] == 1.0f) {
+      n_r += 1.f;
+      for (int k = 0; k < 4; k++) s_r += smooth_l1_sigma3(pr[(int64_t)n * 4 + k] - gr[(int64_t)n * 5 + k]);
+    }
+    if ((int)rintf(gt[(int64_t)n * (R + 6) + R + 5]) == 1) {
+      n_t += 1.f;
+      for (int k = 0; k < 3; k++) {
+        const float d = fabsf(pt[(int64_t)n * (R + 3) + R + k] - gt[(int64_t)n * (R + 6) + R + k]);
+        s_t += d < 1.0f ? 0.5f * d * d : d - 0.5f;
+      }
+    }
+    if (gh && ph && gh[(int64_t)n * (H + 1) + H] == 1.0f) {
+      n_h += 1.f;
+      for (int k = 0; k < H; k++) s_h += smooth_l1_sigma3(ph[(int64_t)n * H + k] - gh[(int64_t)n * (H + 1) + k]);
+    }
+  }
+  s_f = block_sum(s_f, red); s_r = block_sum(s_r, red); s_t = block_sum(s_t, red); s_h = block_sum(s_h, red);
+  n_c = block_sum(n_c, red); n_r = block_sum(n_r, red); n_t = block_sum(n_t, red); n_h = block_sum(n_h, red);
+
+  // ---- pass 2: rotation - the object anchors in ascending order, LOSS_LIST at a time ----
+  const int per = (N + LOSS_THREADS - 1) / LOSS_THREADS, n0 = t * per, n1 = min(N, n0 + per);     // a contiguous run per lane
+  int mine = 0;
+  for (int n = n0; n < n1; n++) mine += (int)rintf(gt[(int64_t)n * (R + 6) + R + 5]) == 1 ? 1 : 0;
+  scan[t] = mine;
+  __syncthreads();
+  for (int o = 1; o < LOSS_THREADS; o <<= 1) {                       // inclusive scan
+    const int v = t >= o ? scan[t - o] : 0;
+    __syncthreads();
+    scan[t] += v;
+    __syncthreads();
+  }
+  const int first = scan[t] - mine, total = scan[LOSS_THREADS - 1];
+  float rot_sum = 0.f;
+  for (int base = 0; base < total; base += LOSS_LIST) {
+    __syncthreads();
+    int ord = first;
+    for (int n = n0; n < n1; n++)
+      if ((int)rintf(gt[(int64_t)n * (R + 6) + R + 5]) == 1) { if (ord >= base && ord < base + LOSS_LIST) list[ord - base] = n; ord++; }
+    __syncthreads();
+    const int cnt = min(LOSS_LIST, total - base);
+    for (int i = 0; i < cnt; i++) {
+      const int n = list[i];
+      const float* g = gt + (int64_t)n * (R + 6);
+      const AxisAngle qp = axis_angle(pt + (int64_t)n * (R + 3)), qt = axis_angle(g);
+      const bool sym = (int)rintf(g[R + 3]) == 1;
+      const int cls = min(max((int)rintf(g[R + 4]), 0), a.classes - 1);
+      const float* pts = a.points + (int64_t)cls * a.P * 3;
+      __syncthreads();
+      for (int j = t; j < a.P; j += LOSS_THREADS) rotate_pt(qt, pts + 3 * j, tgt + 3 * j);
+      __syncthreads();
+      float dsum = 0.f;
+      for (int j = t; j < a.P; j += LOSS_THREADS) {
+        float o[3];
+        rotate_pt(qp, pts + 3 * j, o);
+        float d;
+        if (sym) {
+          d = INFINITY;
+          for (int q = 0; q < a.P; q++) {
+            const float dx = o[0] - tgt[3 * q], dy = o[1] - tgt[3 * q + 1], dz = o[2] - tgt[3 * q + 2];
+            d = fminf(d, sqrtf((dx * dx + dy * dy) + dz * dz));
+          }
+        } else {
+          const float dx = o[0] - tgt[3 * j], dy = o[1] - tgt[3 * j + 1], dz = o[2] - tgt[3 * j + 2];
+          d = sqrtf((dx * dx + dy * dy) + dz * dz);
+        }
+        dsum += d;
+      }
+      rot_sum += block_sum(dsum, red) / (float)a.P;
+    }
+  }
+  if (t == 0) {
+    float* o = a.per_image + (int64_t)b * 5;
+    float rot = rot_sum / n_t;                       // 0 / 0 without object anchors ...
+    if (rot != rot) rot = 0.f;                       // ... NaN -> 0 (loss.py:424)
+    o[0] = s_f / fmaxf(1.0f, n_c);
+    o[1] = s_r / fmaxf(1.0f, n_r);
+    o[2] = rot;
+    o[3] = s_t / (n_t * 3.0f);                       // NaN without object anchors, like torch's mean of nothing
+    o[4] = s_h / fmaxf(1.0f, n_h);
+  }
+}
+
+__global__ void losses_mean_kernel(LossArgs a) {
+#pragma clang fp contract(off)
+  const int k = threadIdx.x;
+  if (k >= 5) return;
+  float s = 0.f;
+  for (int b = 0; b < a.B; b++) s += a.per_image[(int64_t)b * 5 + k];
+  s /= (float)a.B;
+  a.losses[k] = k == 1 ? s * 50.0f : s;
+}
+
+void launch_losses(const LossArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(losses_kernel, dim3(a.B), dim3(LOSS_THREADS), 0, s, a);
+  hipLaunchKernelGGL(losses_mean_kernel, dim3(1), dim3(64), 0, s, a);
+}

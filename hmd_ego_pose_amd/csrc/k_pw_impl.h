@@ -84,7 +84,6 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
   const float inv_as = F8 ? 1.0f / a.a_scale : 1.0f;                          // a_scale is a power of two: exact
 
   // ---- block / wave -> tile assignment ----
-  constexpr int TILES_PER_BLOCK_N = MODE == 1 ? 4 * NT : NT;
   const int chunksN = a.chunksN;
   const int logical = xcd_remap(blockIdx.x, gridDim.x);     // blocks sharing an A strip stay on one XCD
   const int mblk = udiv_rcp(logical, a.chunksN_rcp), nchunk = logical - mblk * chunksN;   // (launch_pw_prec made the reciprocal)

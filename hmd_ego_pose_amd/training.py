@@ -3,8 +3,11 @@
 ``anchor_targets`` is ``anchor_targets_bbox`` (pytorch-sandbox/generators/utils/anchors.py:69-221): the reference builds
 the per-batch classification / regression / transformation / hand targets on the host with numpy and a Cython IoU matrix
 (generators/utils/compute_overlap.pyx:33-73); here the assignment runs in one kernel (csrc/k_eval.hip,
-hep_anchor_targets_device) and its outputs stay on the device for the losses.  The losses themselves
-(hmdegopose/loss.py:54-428) are plain torch code in the reference and keep running through torch autograd - training
+hep_anchor_targets_device) and its outputs stay on the device for the losses.
+
+``losses`` is ``batch_iterate`` (pytorch-sandbox/hmdegopose/loss.py:54-99): the forward VALUES of the focal, box, rotation
+(model-point distance), translation and hand losses, one workgroup per image (hep_losses_device).  The reference computes
+them with a Python loop over the batch and per-image gathers; gradients stay with the caller's autograd - training
 through the HIP forward is out of scope (the inference path has no backward).
 """
 from __future__ import annotations
@@ -53,3 +56,41 @@ def anchor_targets(anchors: torch.Tensor, boxes: Sequence[np.ndarray], labels: S
                                                       float(positive_overlap), lab.data_ptr(), reg.data_ptr(), tra.data_ptr(), _capi.ptr(crd), stream))
     torch.cuda.current_stream(dev).synchronize()      # the staging tensors above must outlive the launch
     return lab, reg, tra, crd
+
+
+def losses(gt_classification: torch.Tensor, classification: torch.Tensor, gt_regression: torch.Tensor, regression: torch.Tensor,
+           gt_transformation: torch.Tensor, transformation: torch.Tensor, gt_hand: Optional[torch.Tensor], hand: Optional[torch.Tensor],
+           model_3d_points, num_rotation_parameter: int = 3):
+    """``batch_iterate`` (hmdegopose/loss.py:54-99) on float32 ROCm tensors laid out as the generator / the network
+    produce them (see include/hep.h: hep_losses_device); ``model_3d_points`` [classes, P, 3] (numpy or tensor).  Returns
+    (losses [5] = classification, regression x 50, rotation, translation, hand - the batch means, per_image [B, 5])."""
+    dev = classification.device
+    def chk(x, name):
+        if x is None:
+            return None
+        if not x.is_cuda or x.dtype != torch.float32:
+            raise ValueError(f"{name} must be a float32 ROCm tensor")
+        return x.contiguous()
+    gc, pc, gr, pr = chk(gt_classification, "gt_classification"), chk(classification, "classification"), chk(gt_regression, "gt_regression"), chk(regression, "regression")
+    gt, pt, gh, ph = chk(gt_transformation, "gt_transformation"), chk(transformation, "transformation"), chk(gt_hand, "gt_hand"), chk(hand, "hand")
+    B, N, K = pc.shape
+    R = int(num_rotation_parameter)
+    if gc.shape != (B, N, K + 1) or gr.shape != (B, N, 5) or pr.shape != (B, N, 4) or gt.shape != (B, N, R + 6) or pt.shape != (B, N, R + 3):
+        raise ValueError("loss inputs do not have the reference's shapes")
+    H = 0
+    if ph is not None:
+        H = int(ph.shape[2])
+        if gh is None or gh.shape != (B, N, H + 1) or ph.shape != (B, N, H):
+            raise ValueError("gt_hand must be [B, N, H + 1] next to hand [B, N, H]")
+    pts = torch.as_tensor(np.asarray(model_3d_points, dtype=np.float32) if not torch.is_tensor(model_3d_points) else model_3d_points,
+                          dtype=torch.float32).to(dev).contiguous()
+    if pts.dim() != 3 or pts.shape[2] != 3:
+        raise ValueError("model_3d_points must be [classes, P, 3]")
+    per = torch.empty((B, 5), dtype=torch.float32, device=dev)
+    out = torch.empty((5,), dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    _capi.check(_capi.lib().hep_losses_device(gc.data_ptr(), pc.data_ptr(), gr.data_ptr(), pr.data_ptr(), gt.data_ptr(), pt.data_ptr(),
+                                              _capi.ptr(gh), _capi.ptr(ph), pts.data_ptr(), B, N, K, R, H, int(pts.shape[0]), int(pts.shape[1]),
+                                              per.data_ptr(), out.data_ptr(), stream))
+    torch.cuda.current_stream(dev).synchronize()      # the contiguous copies above must outlive the launch
+    return out, per

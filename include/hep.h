@@ -22,6 +22,7 @@
  *   hep_filter / _device       <- FilterDetections / filter_detections, pytorch-sandbox/hmdegopose/layers.py:264-482
  *                                 (C# twin Program.cs:472-627)
  *   hep_anchor_targets_device  <- anchor_targets_bbox, pytorch-sandbox/generators/utils/anchors.py:69-221 (training side)
+ *   hep_losses_device          <- batch_iterate, pytorch-sandbox/hmdegopose/loss.py:54-428 (training side, forward values)
  *   hep_pose_errors / _device  <- check_6d_pose_add / check_6d_pose_add_s, pytorch-sandbox/eval/common.py:682-746 with
  *                                 c_min_distances, pytorch-sandbox/generators/utils/calc_min_distances.h:24-35 (the
  *                                 metric arithmetic of evaluate.py's loop, eval/common.py:866-1121)
@@ -159,11 +160,28 @@ int hep_pose_errors_device(const float* points, int num_points, const float* rve
  * [batch][2] = (height, width) of the unpadded image.  Outputs as the reference builds them (float32): labels
  * [batch][N][num_classes+1], regression [batch][N][5] = (ty,tx,th,tw,state), transformation [batch][N][num_transform+1],
  * coords [batch][N][64] (may be NULL); the last column is the anchor state: -1 ignore, 0 background, 1 object.
- * The losses (hmdegopose/loss.py:54-428) are torch code in the reference and stay with torch autograd. */
+ * They feed hep_losses_device below. */
 int hep_anchor_targets_device(const float* anchors, int num_anchors, const double* gt_boxes, const int32_t* gt_labels,
                               const float* gt_transform, const float* gt_coords, const int32_t* num_gt, const int32_t* image_hw,
                               int batch, int kmax, int num_classes, int num_transform, double negative_overlap, double positive_overlap,
                               float* labels, float* regression, float* transformation, float* coords, void* stream);
+
+/* batch_iterate, pytorch-sandbox/hmdegopose/loss.py:54-99 - forward values of the five training losses on device
+ * memory (float32, as torch computes them): focal classification loss (102-167), smooth-L1 box regression x 50
+ * (170-219), rotation = mean (nearest, for symmetric objects) model-point distance between the predicted and the target
+ * axis-angle rotation (273-428), translation = torch SmoothL1Loss on the object anchors (NaN when an image has none - the
+ * reference's behaviour), smooth-L1 hand loss (222-271; gt_hand / hand may both be NULL).  Layouts as the generator and
+ * the network produce them: gt_classification [batch][N][num_classes+1], classification [batch][N][num_classes]
+ * (post-sigmoid), gt_regression [batch][N][5], regression [batch][N][4], gt_transformation [batch][N][num_rotation+3+3] =
+ * (rotation, translation, is_symmetric, class index, anchor state), transformation [batch][N][num_rotation+3] =
+ * cat(rotation head, decoded translation) (train.py:49), gt_hand [batch][N][num_hand+1], hand [batch][N][num_hand],
+ * model_points [num_model_classes][num_points][3] (num_points <= 2048).  Outputs: per_image [batch][5] and losses [5] =
+ * (classification, regression, rotation, translation, hand), the batch means.  Backward stays with the caller's
+ * autograd (the reference's optimiser loop, train.py:88-342, is out of scope). */
+int hep_losses_device(const float* gt_classification, const float* classification, const float* gt_regression, const float* regression,
+                      const float* gt_transformation, const float* transformation, const float* gt_hand, const float* hand,
+                      const float* model_points, int batch, int num_anchors, int num_classes, int num_rotation, int num_hand,
+                      int num_model_classes, int num_points, float* per_image, float* losses, void* stream);
 
 /* preprocess_image (reference generators/colibri_common.py:622-656): device uint8 RGB [batch, height, width, 3] ->
  * device float32 [batch, size, size, 3]: resize by scale = size / max(height, width) (8-bit bilinear, OpenCV

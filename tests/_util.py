@@ -102,3 +102,40 @@ def make_linemod_folder(root, n=5, size=256, seed=0, binary_ply=True):
     with open(os.path.join(obj, "test_0.txt"), "w") as f:
         f.write("\n".join(names) + "\n")
     return pts, truth
+
+
+def loss_cases():
+    """Seeded predictions / targets for the training-side losses (hmdegopose/loss.py:54-428): name -> dict of float32
+    arrays.  Shared by tests/golden/make_golden_losses.py (the real reference), the oracle test and the GPU test."""
+    out = {}
+    for name, B, N, K, P, npos, seed in (("typical", 3, 2000, 2, 60, 24, 1), ("empty", 2, 500, 1, 20, 0, 2),
+                                         ("full", 2, 12276, 1, 500, 40, 3), ("one_positive", 1, 777, 1, 33, 1, 4)):
+        rng = np.random.Generator(np.random.PCG64([seed, 0x10555]))
+        state = np.zeros((B, N), np.float32)
+        for b in range(B):
+            state[b, rng.choice(N, size=N // 10, replace=False)] = -1.0          # ignore
+            if npos:
+                state[b, rng.choice(N, size=npos + b, replace=False)] = 1.0       # object (a different count per image)
+        cls = rng.integers(0, K, size=(B, N))
+        labels = np.zeros((B, N, K), np.float32)
+        pos = state == 1
+        labels[pos, cls[pos]] = 1.0
+        gt_classification = np.concatenate([labels, state[..., None]], axis=2)
+        gt_regression = np.concatenate([rng.standard_normal((B, N, 4)).astype(np.float32) * 0.3, state[..., None]], axis=2)
+        rot_t = rng.uniform(-1, 1, (B, N, 3)).astype(np.float32)
+        tr_t = (rng.standard_normal((B, N, 3)) * 100).astype(np.float32)
+        sym = rng.integers(0, 2, size=(B, N, 1)).astype(np.float32)
+        gt_transformation = np.concatenate([rot_t, tr_t, sym, cls[..., None].astype(np.float32), state[..., None]], axis=2)
+        gt_hand = np.concatenate([(rng.standard_normal((B, N, 63)) * 0.2).astype(np.float32), state[..., None]], axis=2)
+        out[name] = dict(
+            gt_classification=gt_classification.astype(np.float32),
+            classification=(1.0 / (1.0 + np.exp(-rng.standard_normal((B, N, K)) * 3))).astype(np.float32),
+            gt_regression=gt_regression.astype(np.float32),
+            regression=(gt_regression[..., :4] + rng.standard_normal((B, N, 4)) * 0.15).astype(np.float32),
+            gt_transformation=gt_transformation.astype(np.float32),
+            transformation=np.concatenate([rot_t + rng.standard_normal((B, N, 3)).astype(np.float32) * 0.1,
+                                           tr_t + rng.standard_normal((B, N, 3)).astype(np.float32) * 5], axis=2).astype(np.float32),
+            gt_hand=gt_hand.astype(np.float32),
+            hand=(gt_hand[..., :63] + rng.standard_normal((B, N, 63)) * 0.1).astype(np.float32),
+            model_points=(rng.standard_normal((K, P, 3)) * np.array([40, 25, 60])).astype(np.float32))
+    return out

@@ -220,3 +220,25 @@ def test_anchor_targets_match_the_imported_reference():
     boxes = np.stack([anchors[4000].astype(np.float64), np.array([1000., 1000., 1010., 1010.])])
     pos, ign, arg = T.compute_gt_annotations(anchors, boxes)
     assert pos[4000] and arg[4000] == 0 and pos[0] and np.allclose(T.bbox_transform(anchors, boxes[arg, :])[4000], 0, atol=1e-6)
+
+
+def test_losses_match_the_imported_reference():
+    """oracle/train_ref.py::batch_losses against the REAL reference's batch_iterate (hmdegopose/loss.py:54-428), replayed
+    from tests/golden/losses.npz (made by tests/golden/make_golden_losses.py on the seeded cases of tests/_util.py):
+    typical images, an image batch without a single object anchor (rotation 0, translation NaN - what the reference
+    returns), the full 12 276-anchor grid with 500 model points, one object anchor.  float32 in another summation
+    order: relative 1e-5."""
+    import os
+    from oracle import train_ref as T
+    from tests._util import loss_cases
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "losses.npz"))
+    cases = loss_cases()
+    assert set(cases) == set(fx.files)
+    for name, c in cases.items():
+        got = T.batch_losses(c["gt_classification"], c["classification"], c["gt_regression"], c["regression"], c["gt_transformation"],
+                             c["transformation"], c["gt_hand"], c["hand"], c["model_points"], 3)
+        want = fx[name]
+        assert np.array_equal(np.isnan(got), np.isnan(want)), (name, got, want)
+        ok = ~np.isnan(want)
+        assert np.allclose(got[ok], want[ok], rtol=1e-5, atol=1e-7), (name, got, want)
+    assert np.isnan(fx["empty"][3]) and fx["empty"][2] == 0.0

@@ -651,6 +651,41 @@ def test_anchor_targets_match_oracle(api):
     assert (st == 1).sum() > 0 and (st == -1).sum() > 0 and st[2].max() <= 0          # image 2 has no boxes: nothing positive
 
 
+def test_losses_match_oracle_and_reference():
+    """Training-side losses on the GPU (hep_losses_device = batch_iterate, hmdegopose/loss.py:54-428) against the oracle
+    restatement and against the values the REAL reference returned for the same seeded cases (tests/golden/losses.npz):
+    relative 2e-5 (float32 sums in another order, device cos / sin / pow / log); NaN exactly where the reference has it
+    (translation loss of a batch with an image without object anchors); the launch is bit-reproducible."""
+    import os
+    from hmd_ego_pose_amd.training import losses
+    from oracle import train_ref as T
+    from tests._util import loss_cases
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "losses.npz"))
+    for name, c in loss_cases().items():
+        d = {k: torch.from_numpy(v).cuda() for k, v in c.items() if k != "model_points"}
+        args = (d["gt_classification"], d["classification"], d["gt_regression"], d["regression"], d["gt_transformation"], d["transformation"],
+                d["gt_hand"], d["hand"], c["model_points"], 3)
+        out, per = losses(*args)
+        out2, per2 = losses(*args)
+        got = out.cpu().numpy().astype(np.float64)
+        assert np.array_equal(out.cpu().numpy(), out2.cpu().numpy(), equal_nan=True) and np.array_equal(per.cpu().numpy(), per2.cpu().numpy(), equal_nan=True)
+        want_o = T.batch_losses(c["gt_classification"], c["classification"], c["gt_regression"], c["regression"], c["gt_transformation"],
+                                c["transformation"], c["gt_hand"], c["hand"], c["model_points"], 3).astype(np.float64)
+        for want, what in ((want_o, "oracle"), (fx[name], "reference")):
+            assert np.array_equal(np.isnan(got), np.isnan(want)), (name, what, got, want)
+            ok = ~np.isnan(want)
+            assert np.allclose(got[ok], want[ok], rtol=2e-5, atol=1e-6), (name, what, got, want)
+        print(name, got)
+    # without the hand branch (gt_hand = hand = None) the other four are unchanged and the hand loss is 0
+    c = loss_cases()["typical"]
+    d = {k: torch.from_numpy(v).cuda() for k, v in c.items() if k != "model_points"}
+    full, _ = losses(d["gt_classification"], d["classification"], d["gt_regression"], d["regression"], d["gt_transformation"], d["transformation"],
+                     d["gt_hand"], d["hand"], c["model_points"], 3)
+    nohand, _ = losses(d["gt_classification"], d["classification"], d["gt_regression"], d["regression"], d["gt_transformation"], d["transformation"],
+                       None, None, c["model_points"], 3)
+    assert torch.equal(full[:4], nohand[:4]) and float(nohand[4]) == 0.0
+
+
 def test_two_gpu_rccl_bench_line():
     """bench.py --gpus 2 on a box with two or more MI355X: the script starts its own rank processes, the weights are
     broadcast and the frames scattered / detections gathered over RCCL (backend nccl), rank 0 prints one JSON line.
