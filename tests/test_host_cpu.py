@@ -188,3 +188,79 @@ def test_evaluator_host_logic(tmp_path):
     assert s_.tolist() == [np.float32(0.9), np.float32(0.7), np.float32(0.7), np.float32(0.3)]
     assert np.array_equal(b, ob) and np.array_equal(s_, os_) and np.array_equal(r, orr) and np.array_equal(t, ot)
     assert np.array_equal(b[1], det["boxes"][2].numpy() / np.float32(0.8))         # equal scores: lower row first
+
+
+# ---- ONNX initialiser reader ----
+def _pb_varint(v):
+    v &= (1 << 64) - 1
+    out = bytearray()
+    while True:
+        c = v & 0x7F; v >>= 7
+        out.append(c | (0x80 if v else 0))
+        if not v:
+            return bytes(out)
+
+
+def _pb_field(num, wt, payload):
+    return _pb_varint((num << 3) | wt) + (payload if wt == 0 else _pb_varint(len(payload)) + payload)
+
+
+def _onnx_tensor(name, arr, how):
+    """TensorProto per the published onnx.proto: dims 1, data_type 2, float_data 4, int64_data 7, name 8, raw_data 9."""
+    dt = {np.dtype("float32"): 1, np.dtype("int64"): 7, np.dtype("float16"): 10}[arr.dtype]
+    if how == "packed_dims":
+        body = _pb_field(1, 2, b"".join(_pb_varint(int(d)) for d in arr.shape))
+    else:
+        body = b"".join(_pb_field(1, 0, _pb_varint(int(d))) for d in arr.shape)
+    body += _pb_field(2, 0, _pb_varint(dt))
+    if how == "float_data" and dt == 1:
+        body += _pb_field(4, 2, arr.astype("<f4").tobytes())
+    elif how == "int64_data" and dt == 7:
+        body += _pb_field(7, 2, b"".join(_pb_varint(int(x)) for x in arr.reshape(-1)))
+    else:
+        body += _pb_field(9, 2, arr.astype(arr.dtype.newbyteorder("<")).tobytes())
+    return body + _pb_field(8, 2, name.encode())
+
+
+def _onnx_model(tensors):
+    graph = _pb_field(1, 2, _pb_field(4, 2, b"Conv"))                       # a node in front of the initialisers (skipped)
+    graph += _pb_field(2, 2, b"main_graph")
+    for name, arr, how in tensors:
+        graph += _pb_field(5, 2, _onnx_tensor(name, arr, how))
+    return _pb_field(1, 0, _pb_varint(7)) + _pb_field(2, 2, b"pytorch") + _pb_field(7, 2, graph) + _pb_field(8, 2, _pb_field(2, 0, _pb_varint(11)))
+
+
+def test_onnx_initializer_reader_roundtrip_and_pack(tmp_path):
+    """hmd_ego_pose_amd/onnx_init.py against files written here from the published onnx.proto layout (PARITY UNPINNED: no
+    real exporter output exists in this build): raw_data / float_data / int64_data encodings, packed and unpacked dims,
+    negative int64, a scalar; then a whole phi-0 state_dict with `model.` prefixes through tools/pack_weights.py's path,
+    and the refusal of a file whose initialisers are anonymous (eval-mode export with BatchNorm folded)."""
+    import torch
+    from hmd_ego_pose_amd import param_spec, seeded_state_dict
+    from hmd_ego_pose_amd.onnx_init import read_initializers, state_dict_from_onnx
+    from hmd_ego_pose_amd.weights import load_pack, pack_bytes
+    rng = np.random.default_rng(0)
+    ts = [("a.weight", rng.standard_normal((4, 3, 3, 3)).astype(np.float32), "raw"),
+          ("b.bias", rng.standard_normal((7,)).astype(np.float32), "float_data"),
+          ("c.num_batches_tracked", np.array(-5, dtype=np.int64), "int64_data"),
+          ("d.idx", np.array([[1, -2], [3, 1 << 40]], dtype=np.int64), "packed_dims"),
+          ("e.half", rng.standard_normal((2, 5)).astype(np.float16), "raw")]
+    got = read_initializers(_onnx_model(ts))
+    assert list(got) == [t[0] for t in ts]
+    for name, arr, _ in ts:
+        assert got[name].dtype == arr.dtype and got[name].shape == arr.shape and np.array_equal(got[name], arr), name
+    with pytest.raises(ValueError):
+        read_initializers(_onnx_model(ts)[:-40] + b"\xff")                  # truncated / corrupt
+    with pytest.raises(ValueError):
+        read_initializers(b"\x0a\x03abc")                                   # not a ModelProto with a graph
+    # a whole network: every state_dict entry as an initialiser, `model.` prefixed like TrainModelWithLoss saves them
+    sd = seeded_state_dict(0, 3)
+    blob = _onnx_model([("model." + k, v.numpy(), "raw" if i % 2 else ("float_data" if v.dtype == torch.float32 else "int64_data")) for i, (k, v) in enumerate(sd.items())])
+    path = tmp_path / "m.onnx"; path.write_bytes(blob)
+    state = state_dict_from_onnx(str(path), 0)
+    assert set(state) == {k for k, _ in param_spec(0)} and all(torch.equal(state[k], sd[k]) for k in state)
+    a, b = load_pack(pack_bytes(state)), load_pack(pack_bytes(sd))
+    assert a.keys() == b.keys() and all(np.array_equal(a[k], b[k]) for k in a)
+    anon = _onnx_model([(f"onnx::Conv_{i}", v.numpy(), "raw") for i, (k, v) in enumerate(sd.items()) if v.dtype == torch.float32])
+    with pytest.raises(ValueError, match="anonymous"):
+        state_dict_from_onnx(anon, 0)

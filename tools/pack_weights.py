@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Convert a reference checkpoint (.pth state_dict, keys un-prefixed, `model.` or `model.module.`
-prefixed - pytorch-sandbox/evaluate.py:102-116) into the HEPW weight pack that libhep.so reads.
+prefixed - pytorch-sandbox/evaluate.py:102-116) or an exported .onnx whose initialisers carry the state_dict
+names (hmd_ego_pose_amd/onnx_init.py) into the HEPW weight pack that libhep.so reads.
 
     python tools/pack_weights.py weights/syn_colibri/fold_0/phi_0_....pth model.hepw --phi 0
 """
@@ -19,7 +20,11 @@ def main():
     a = ap.parse_args()
     import torch
     from hmd_ego_pose_amd import param_spec, save_pack, strip_checkpoint_prefix
-    state = strip_checkpoint_prefix(torch.load(a.checkpoint, map_location="cpu", weights_only=True))
+    if a.checkpoint.lower().endswith(".onnx"):
+        from hmd_ego_pose_amd.onnx_init import state_dict_from_onnx
+        state = state_dict_from_onnx(a.checkpoint, a.phi)
+    else:
+        state = strip_checkpoint_prefix(torch.load(a.checkpoint, map_location="cpu", weights_only=True))
     want = dict(param_spec(a.phi))
     missing = [k for k in want if k not in state and not k.endswith("num_batches_tracked")]
     wrong = [k for k in want if k in state and tuple(state[k].shape) != want[k]]
