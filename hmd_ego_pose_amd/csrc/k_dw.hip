@@ -104,9 +104,19 @@ __global__ __launch_bounds__(256) void dw_kernel(DwArgs a) {
   constexpr int WIN = (TW - 1) * S + KS;
 
   // every lane needs the K*K weight vectors of its channel group: staged in LDS once per workgroup
-  // (as global loads they were half of all vector-memory instructions of the kernel)
-  for (int i = threadIdx.x; i < (KS * KS * a.C) >> 2; i += 256) reinterpret_cast<f32x4*>(w_s)[i] = reinterpret_cast<const f32x4*>(a.w)[i];
-  for (int i = threadIdx.x; i < a.C >> 2; i += 256) reinterpret_cast<f32x4*>(w_s + KS * KS * a.C)[i] = reinterpret_cast<const f32x4*>(a.bias)[i];
+  // (as global loads they were half of all vector-memory instructions of the kernel); both requests leave before the
+  // first store waits (they were two dependent round trips)
+  {
+    const int nwv = (KS * KS * a.C) >> 2, nbv = a.C >> 2;
+    const f32x4* wg = reinterpret_cast<const f32x4*>(a.w);
+    const f32x4 v0 = wg[min((int)threadIdx.x, nwv - 1)], v1 = wg[min((int)threadIdx.x + 256, nwv - 1)];
+    const f32x4 vb = reinterpret_cast<const f32x4*>(a.bias)[min((int)threadIdx.x, nbv - 1)];
+    if ((int)threadIdx.x < nwv) reinterpret_cast<f32x4*>(w_s)[threadIdx.x] = v0;
+    if ((int)threadIdx.x + 256 < nwv) reinterpret_cast<f32x4*>(w_s)[threadIdx.x + 256] = v1;
+    for (int i = threadIdx.x + 512; i < nwv; i += 256) reinterpret_cast<f32x4*>(w_s)[i] = wg[i];
+    if ((int)threadIdx.x < nbv) reinterpret_cast<f32x4*>(w_s + KS * KS * a.C)[threadIdx.x] = vb;
+    for (int i = threadIdx.x + 256; i < nbv; i += 256) reinterpret_cast<f32x4*>(w_s + KS * KS * a.C)[i] = reinterpret_cast<const f32x4*>(a.bias)[i];   // (C > 1024)
+  }
   __syncthreads();
 
   float acc[TW][8];
@@ -117,11 +127,28 @@ __global__ __launch_bounds__(256) void dw_kernel(DwArgs a) {
   float sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
   if (valid) {
-    const int64_t img = (int64_t)b * a.H * a.W * a.C;
-#pragma unroll
-    for (int ky = 0; ky < KS; ky++) {
+    // One row of taps at a time: its WIN input vectors are requested together, UNCONDITIONALLY on clamped addresses
+    // (taps outside the image are zeroed by a select), then consumed.  As first written every tap load sat under its own
+    // bounds check and the compiler waited for each one before the next (18 dependent round trips per lane for 3x3 and
+    // four pixels: the kernel lived on occupancy alone); with no condition at all and the rows unrolled it hoisted all
+    // 18 loads (196 VGPRs, two waves per SIMD, slower).  The row loop is a real loop: WIN raw vectors live at a time.
+    typedef typename std::conditional<BF16, u32x4, f32x4>::type raw_t;
+    typedef typename V::elem T;
+    const unsigned char* in_b = reinterpret_cast<const unsigned char*>(a.in) + (int64_t)b * a.H * a.W * a.C * (int)sizeof(T);
+    auto load_row = [&](int ky, raw_t* x0, raw_t* x1) {
       const int iy = oy * S - a.pad_t + ky;
-      if (iy < 0 || iy >= a.H) continue;
+      const uint32_t rowoff = (uint32_t)(min(max(iy, 0), a.H - 1) * a.W);
+#pragma unroll
+      for (int c0 = 0; c0 < WIN; c0++) {
+        const int ix = ox0 * S - a.pad_l + c0;
+        const unsigned char* src = in_b + (size_t)((rowoff + (uint32_t)min(max(ix, 0), a.W - 1)) * (uint32_t)a.C + (uint32_t)(cg * 8)) * sizeof(T);
+        x0[c0] = *reinterpret_cast<const raw_t*>(src);
+        if (!BF16) x1[c0] = *reinterpret_cast<const raw_t*>(src + 16);
+      }
+    };
+    auto use_row = [&](int ky, const raw_t* xr0, const raw_t* xr1) {
+      const int iy = oy * S - a.pad_t + ky;
+      const bool rok = iy >= 0 && iy < a.H;
       float w[KS][8];
 #pragma unroll
       for (int kx = 0; kx < KS; kx++) {
@@ -133,9 +160,15 @@ __global__ __launch_bounds__(256) void dw_kernel(DwArgs a) {
 #pragma unroll
       for (int c0 = 0; c0 < WIN; c0++) {
         const int ix = ox0 * S - a.pad_l + c0;
-        if (ix < 0 || ix >= a.W) continue;
+        const bool ok = rok && ix >= 0 && ix < a.W;
         float x[8];
-        V::load(a.in, img + ((int64_t)iy * a.W + ix) * a.C + cg * 8, x);
+        if constexpr (BF16) {
+#pragma unroll
+          for (int q = 0; q < 4; q++) { x[2 * q] = ok ? __uint_as_float(xr0[c0][q] << 16) : 0.f; x[2 * q + 1] = ok ? __uint_as_float(xr0[c0][q] & 0xffff0000u) : 0.f; }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; q++) { x[q] = ok ? xr0[c0][q] : 0.f; x[4 + q] = ok ? xr1[c0][q] : 0.f; }
+        }
 #pragma unroll
         for (int kx = 0; kx < KS; kx++) {
           if ((c0 - kx) % S != 0 || c0 - kx < 0) continue;
@@ -145,7 +178,11 @@ __global__ __launch_bounds__(256) void dw_kernel(DwArgs a) {
           for (int c = 0; c < 8; c++) acc[p][c] = fmaf(x[c], w[kx][c], acc[p][c]);
         }
       }
-    }
+    };
+    raw_t cur0[WIN], cur1[WIN];
+#pragma unroll 1      // a real loop: unrolled, all rows' loads are hoisted together (196 VGPRs, two waves per SIMD, 25 us);
+                      // two rows in flight (double buffer) cost 137 VGPRs, three waves per SIMD: 18.0 us against 15.5
+    for (int ky = 0; ky < KS; ky++) { load_row(ky, cur0, cur1); use_row(ky, cur0, cur1); }
     float bias[8];
     {
       const f32x4* bp = reinterpret_cast<const f32x4*>(w_s + KS * KS * a.C + cg * 8);
