@@ -194,6 +194,11 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
       }
     };
     issue(0, 0);
+    // the two bias vectors as well (they sat behind the barriers: two more dependent round trips in the chain)
+    const float br_v = a.se_br[min((int)threadIdx.x, sq - 1)];
+    float be_v[RB];
+#pragma unroll
+    for (int rr = 0; rr < RB; rr++) be_v[rr] = a.se_be[min((rr << 8) + (int)threadIdx.x, K - 1)];
     for (int img = img0; img <= img1; img++) {
       // hidden[j] = swish(inv_hw * sum_rows hpart[img][row][j] + br[j]): G groups each add every G-th row,
       // then the groups are added up - fixed order
@@ -213,7 +218,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
         if (threadIdx.x < sq) {
           float sacc = 0.f;
           for (int q = 0; q < G; q++) sacc += red_s[q * sqp + threadIdx.x];
-          h = swishf(fmaf(sacc, a.inv_hw, a.se_br[threadIdx.x]));
+          h = swishf(fmaf(sacc, a.inv_hw, br_v));
         }
         hid_s[threadIdx.x] = h;                  // padding entries are exact zeros
       }
@@ -251,7 +256,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
 #pragma unroll
         for (int rr = 0; rr < RB; rr++) {
           const int k = ((r0 + rr) << 8) + threadIdx.x;
-          if (k < K) sc[k] = sigmoidf((e[rr][0] + e[rr][1]) + a.se_be[k]);
+          if (k < K) sc[k] = sigmoidf((e[rr][0] + e[rr][1]) + (r0 == 0 ? be_v[rr] : a.se_be[k]));
         }
       }
       __syncthreads();
