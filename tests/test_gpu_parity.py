@@ -686,6 +686,36 @@ def test_losses_match_oracle_and_reference():
     assert torch.equal(full[:4], nohand[:4]) and float(nohand[4]) == 0.0
 
 
+def test_losses_many_object_anchors_and_large_models():
+    """hep_losses_device past its internal batch sizes: 2 500 object anchors in one image (the compacted list holds 2 048 at
+    a time) and 1 500 model points per class (a lane rotates more than one point; the limit is 2 048), against the oracle."""
+    from hmd_ego_pose_amd.training import losses
+    from oracle import train_ref as T
+    rng = np.random.Generator(np.random.PCG64(99))
+    B, N, K, P = 2, 6000, 1, 1500
+    state = np.zeros((B, N), np.float32)
+    state[0, rng.choice(N, size=2500, replace=False)] = 1.0
+    state[1, rng.choice(N, size=3, replace=False)] = 1.0
+    labels = (state == 1).astype(np.float32)[..., None]
+    gt_c = np.concatenate([labels, state[..., None]], 2)
+    gt_r = np.concatenate([rng.standard_normal((B, N, 4)).astype(np.float32) * 0.3, state[..., None]], 2)
+    rot = rng.uniform(-1, 1, (B, N, 3)).astype(np.float32); tr = (rng.standard_normal((B, N, 3)) * 50).astype(np.float32)
+    sym = np.zeros((B, N, 1), np.float32); sym[1] = 1.0                      # the 3 symmetric ones: 1500 x 1500 distances each
+    gt_t = np.concatenate([rot, tr, sym, np.zeros((B, N, 1), np.float32), state[..., None]], 2)
+    cls = (1 / (1 + np.exp(-rng.standard_normal((B, N, K))))).astype(np.float32)
+    reg = (gt_r[..., :4] + rng.standard_normal((B, N, 4)) * 0.1).astype(np.float32)
+    tra = np.concatenate([rot + rng.standard_normal((B, N, 3)).astype(np.float32) * 0.05, tr + rng.standard_normal((B, N, 3)).astype(np.float32) * 2], 2).astype(np.float32)
+    pts = (rng.standard_normal((1, P, 3)) * 30).astype(np.float32)
+    c = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    out, per = losses(c(gt_c), c(cls), c(gt_r), c(reg), c(gt_t), c(tra), None, None, pts, 3)
+    want = T.batch_losses(gt_c, cls, gt_r, reg, gt_t, tra, np.zeros((B, N, 2), np.float32), np.zeros((B, N, 1), np.float32), pts, 3)
+    got = out.cpu().numpy()
+    assert np.allclose(got[:4], want[:4], rtol=5e-5, atol=1e-6), (got, want)
+    from hmd_ego_pose_amd import _capi
+    with pytest.raises(_capi.HepError):
+        losses(c(gt_c), c(cls), c(gt_r), c(reg), c(gt_t), c(tra), None, None, np.zeros((1, 2049, 3), np.float32), 3)
+
+
 def test_two_gpu_rccl_bench_line():
     """bench.py --gpus 2 on a box with two or more MI355X: the script starts its own rank processes, the weights are
     broadcast and the frames scattered / detections gathered over RCCL (backend nccl), rank 0 prints one JSON line.
