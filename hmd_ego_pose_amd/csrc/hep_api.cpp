@@ -686,14 +686,14 @@ int hep_kernel_symbol(const hep_handle* h, int i, const char** symbol) {
   const int prec = o.kind == OP_PW ? (o.pw.fp8 ? 2 : (h->s.dtype ? 1 : 0)) : 0;
   char tmp[128];
   switch (o.kind) {
-    case OP_STEM: if (stem_uses_mfma(o.stem.Cout)) snprintf(tmp, sizeof tmp, "stem_kernel<%s, %d>", t, (o.stem.Cout + 15) / 16);
+    case OP_STEM: if (o.stem.mfma) snprintf(tmp, sizeof tmp, "stem_kernel<%s, %d>", t, (o.stem.Cout + 15) / 16);
                   else snprintf(tmp, sizeof tmp, "stem_valu_kernel<%s>", t);
                   break;
     case OP_PW: snprintf(tmp, sizeof tmp, "pw_gemm_kernel<%d, %d, %d, %d, %d, %d>", prec, o.pw.MT, o.pw.NT, o.pw.mode, o.pw.act == ACT_SWISH ? 1 : 0, pw_se_variant(o.pw)); break;
     case OP_DW: snprintf(tmp, sizeof tmp, "dw_kernel<%s, %d, %d, %d>", t, o.dw.k, o.dw.s, o.dw.TW); break;
     case OP_POOL: snprintf(tmp, sizeof tmp, "pool_kernel<%s>", t); break;
     case OP_PWG: snprintf(tmp, sizeof tmp, "pw_group_kernel<%s>", t); break;
-    case OP_CHAIN: snprintf(tmp, sizeof tmp, "chain_kernel"); break;
+    case OP_CHAIN: snprintf(tmp, sizeof tmp, "chain_kernel<%s, %s>", o.chain.bf16 ? "true" : "false", o.chain.stream_w ? "true" : "false"); break;
     case OP_SE: snprintf(tmp, sizeof tmp, "se_finish_kernel<%s>", t); break;
     case OP_MBF: snprintf(tmp, sizeof tmp, "mbf_kernel<%s, %d, %d, %d>", t, o.mbf.k, o.mbf.s, o.mbf.ts); break;
     case OP_SBF: snprintf(tmp, sizeof tmp, "sbf_kernel<%s>", t); break;

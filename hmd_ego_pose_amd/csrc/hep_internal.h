@@ -25,6 +25,7 @@ struct StemArgs {
   void* out;           // [B,Ho,Wo,Cout]
   int B, H, W, Ho, Wo, Cout, pad_t, pad_l, bf16;
   int mpw; uint32_t tx_rcp, ho_rcp;          // filled by launch_stem: m-tiles per wave, rcp_u32 of m-tiles per row and of Ho
+  int mfma;                                  // plan: 1 = stem_kernel (MFMA form), 0 = stem_valu_kernel (stem_uses_mfma() when the plan is built)
 };
 
 // ---- stem conv + block 0's depthwise conv as one launch (k_sbf.hip): the stem's output never reaches HBM ----
@@ -125,6 +126,7 @@ struct XbfArgs {
   int chunk_tiles, nchunks;                                         // expanded n-tiles per LDS chunk (<= 2 chunks)
   uint32_t tiles_rcp, tiles_x_rcp, sw_rcp;                          // rcp_u32 of workgroups per image, tiles_x, lane sweeps per input tile row
   int trace;                                                         // profiling builds: this launch writes its phase stamps
+  int generic;                                                       // plan: 1 = the generic instantiation although a shape-specialised one exists (HEP_XBF_GENERIC, A/B and parity runs)
   int off_w1, off_w2, off_f, off_misc; size_t lds_bytes;            // LDS: [a_s | e_s union][blob: w1 | w2 | floats][scale, hidden, red, csum]
 };
 size_t xbf_layout(XbfArgs* a);                   // fills the LDS offsets / chunking from the shapes; returns lds_bytes (0: does not fit)
@@ -132,6 +134,7 @@ int xbf_supports(int k, int s);                  // tile instantiations
 void xbf_tile(int k, int s, int* toh, int* tow);
 void launch_xbf(const XbfArgs&, hipStream_t);
 int xbf_prepare(void);
+int xbf_generic_forced(void);                 // HEP_XBF_GENERIC, read when a plan is built
 int xbf_specialised(const XbfArgs&);          // 1: a shape-specialised instantiation exists (names the device function)
 
 // ---- 3x3 s2 max-pool, TF-SAME with ZERO padding (utils_extra.py:72-86) ----
@@ -166,7 +169,7 @@ struct SepArgs {
   size_t off_wpw;                            // 0, or where the node's pointwise weights [C][C + pad] are staged (bf16 nodes wider than 64 that fit)
 };
 
-// ---- LDS-resident chain of small-level BiFPN nodes, one workgroup per image (k_chain.hip, bf16 sessions) ----
+// ---- LDS-resident chain of small-level BiFPN nodes, one workgroup per image (k_chain.hip) ----
 #define CH_MAX_NODES 8
 #define CH_MAX_EXT 8
 struct ChainSrc { int off, kind, sh, sw; float fw; };    // LDS slot (element offset) holding the source map at sh x sw; kind relative to the node's size
@@ -183,6 +186,7 @@ struct ChainArgs {
   const ChainNode* nodes; const void* wblob;             // device: node table, the nodes' weights in LDS layout
   ChainExt ext[CH_MAX_EXT];
   int nnodes, nconv, next, B, C, wnode_bytes;           // nconv: nodes with a convolution (the others are plain max-pools)
+  int bf16, stream_w;                                    // session dtype; stream_w: LDS holds ONE node's weights, the next node's arrive under the running one
   uint32_t nt_rcp;                                       // rcp_u32(ceil(C / 16)): (m-tile, n-tile) pair -> m-tile (filled by launch_chain)
   size_t off_w, off_halo, off_atile, lds_bytes;
 };

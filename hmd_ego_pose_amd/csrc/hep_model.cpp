@@ -297,7 +297,7 @@ struct Planner {
       } else if (ksteps >= 8) {     // small maps, deep K (project): split K over the 4 waves
         // widest split-K tile (HEP_PW_NT2, A/B knob).  Measured at phi 0 b16 (two m-tiles per wave): 4 / 2 / 1 n-tiles ->
         // one batch 0.6312 / 0.6259 / 0.6360 ms, four in flight 48.2k / 48.3k / 47.0k frames/s: 2
-        static const int nt2_max = getenv("HEP_PW_NT2") ? atoi(getenv("HEP_PW_NT2")) : 2;
+        const int nt2_max = getenv("HEP_PW_NT2") ? atoi(getenv("HEP_PW_NT2")) : 2;
         pmode = 2; pMT = 1; pNT = clampi(strips * tilesN / 256, 1, std::min(std::min(8, nt2_max), tilesN));
       } else {                      // small maps, wide N (expand / lateral): waves side by side in N
         pmode = 1; pMT = 1; pNT = clampi(strips * tilesN / (4 * 256), 1, std::min(8, (tilesN + 3) / 4));
@@ -321,7 +321,7 @@ struct Planner {
     if (se) {
       const int rows_wg = pmode == 0 ? 64 * pMT : 16 * pMT, per_n = pmode == 1 ? 4 * pNT : pNT;
       const double wgs = (double)((Mmax + rows_wg - 1) / rows_wg) * ((tilesN + per_n - 1) / per_n);
-      static const double maxmb = getenv("HEP_SE_MAXMB") ? atof(getenv("HEP_SE_MAXMB")) : 4.0;
+      const double maxmb = getenv("HEP_SE_MAXMB") ? atof(getenv("HEP_SE_MAXMB")) : 4.0;      // (plain getenv: the plan is built once per session)
       if (wgs * K * se->sqp * es() > maxmb * 1e6) {
         scale_t = tensor(name + ".se_scale", 1, 1, K, true);
         const int sop = new_op(OP_SE, name.substr(0, name.find('.')) + ".se");
@@ -420,7 +420,7 @@ struct Planner {
   // boundary launch: [SE + project of the deferred block] + [expand + depthwise + SE partial sums of block i] (k_xbf.hip)
   bool try_xbf(int i, const MBConv& b, int dw_t, const std::vector<float>& wdw, const std::vector<float>& bdw, size_t wr_off, int sqp2,
                int Hin, int Win, int Ho, int Wo, int pt, int pl, bool mid_needed, int* part_t, int* nblk) {
-    static const int minh = getenv("HEP_XBF_MINH") ? atoi(getenv("HEP_XBF_MINH")) : 64;     // smallest input map that takes the boundary kernel
+    const int minh = getenv("HEP_XBF_MINH") ? atoi(getenv("HEP_XBF_MINH")) : 64;     // smallest input map that takes the boundary kernel
     const char* e = getenv("HEP_XBF");
     if (e && atoi(e) == 0) return false;
     const MBConv& pb = defer.b;
@@ -430,6 +430,7 @@ struct Planner {
     xa.H = Hin; xa.W = Win; xa.K1 = pb.cexp; xa.N1 = pb.cout; xa.NT1 = (pb.cout + 15) / 16; xa.Cexp = b.cexp; xa.NT2 = b.cexp / 16;
     xa.Ho = Ho; xa.Wo = Wo; xa.k = b.k; xa.s = b.stride; xa.pad_t = pt; xa.pad_l = pl; xa.bf16 = s->dtype;
     xa.se_rows = defer.se.rows; xa.sq = defer.se.sq; xa.sqp = defer.se.sqp; xa.inv_hw = defer.se.inv_hw; xa.sq2 = b.se; xa.sqp2 = sqp2;
+    xa.generic = xbf_generic_forced();
     if (xbf_layout(&xa) == 0) return false;
     xa.tiles_x = (Wo + xa.tow - 1) / xa.tow; xa.tiles = xa.tiles_x * ((Ho + xa.toh - 1) / xa.toh);
     // weights: project of the deferred block (BN2 folded), expand of this block (BN0 folded), depthwise (BN1 folded, by the caller)
@@ -468,7 +469,7 @@ struct Planner {
     {
       // default: two tiles per workgroup where one tile per workgroup would need more than the 512 workgroups the GPU holds at
       // once (two per CU) - the second round then runs in the same workgroups, without their blob / squeeze-excite prologue
-      static const int tpw_env = getenv("HEP_XBF_TPW") ? atoi(getenv("HEP_XBF_TPW")) : 0;
+      const int tpw_env = getenv("HEP_XBF_TPW") ? atoi(getenv("HEP_XBF_TPW")) : 0;
       const int tpw = tpw_env > 0 ? tpw_env : ((int64_t)xa.tiles * s->lane_batch > 512 ? 2 : 1);
       xa.tpw = std::max(1, std::min(tpw, xa.tiles));
     }
@@ -517,7 +518,7 @@ struct Planner {
     // output tile side of the fused front: 16 on the stride-1 layers of 16x16 / 32x32 maps (the whole 16x16 map per
     // workgroup: no halo re-expansion, a quarter of the workgroups and of their fixed staging / drain latency), else 8.
     // HEP_MBF_TS=8 forces the small tile (A/B measurements, parity test of the alternative plan).
-    static const int ts16_maxh = getenv("HEP_MBF_TS16_MAXH") ? atoi(getenv("HEP_MBF_TS16_MAXH")) : 32;     // A/B knob
+    const int ts16_maxh = getenv("HEP_MBF_TS16_MAXH") ? atoi(getenv("HEP_MBF_TS16_MAXH")) : 32;     // A/B knob
     int ts = (b.stride == 1 && b.expand && Ho >= 16 && Ho <= ts16_maxh) ? 16 : 8;
     if (const char* e = getenv("HEP_MBF_TS")) if (atoi(e) == 8) ts = 8;
     int max_in = mbf_max_inside(Hin, Win, b.k, b.stride, pt, pl, ts);   // rows of the compact input tile in LDS
@@ -531,7 +532,7 @@ struct Planner {
     // nothing) and loses on the big early maps (bandwidth-bound, the two-kernel path already streams well;
     // stride-2 halos there cost up to 4.5x recompute).  HEP_MBF=all|none overrides for A/B runs.
     const char* mode = getenv("HEP_MBF");
-    static const int maxh = getenv("HEP_MBF_MAXH") ? atoi(getenv("HEP_MBF_MAXH")) : 32;     // A/B knob: largest input map that takes the fused front
+    const int maxh = getenv("HEP_MBF_MAXH") ? atoi(getenv("HEP_MBF_MAXH")) : 32;     // A/B knob: largest input map that takes the fused front
     const bool want = mode ? !strcmp(mode, "all") : Hin <= maxh;
     if (want && !(mode && !strcmp(mode, "none")))
       for (int cand : {64, 32, 16})
@@ -790,11 +791,22 @@ struct Planner {
   struct PoolSpec { int src_t, out_t, level; };
   bool add_chain(const std::string& name, const std::vector<PoolSpec>& pools, const std::vector<SegSpec>& specs) {
     const int C = s->arch.fpn_w;
-    if (s->dtype == 0 || C % 8 != 0 || specs.empty()) return false;
+    if (C % 8 != 0 || specs.empty()) return false;
+    if (const char* e = getenv("HEP_CHAIN_F32")) if (s->dtype == 0 && atoi(e) == 0) return false;      // A/B knob: fp32 chains back on k_sep.hip
+    // LDS map slots.  Every slot records who writes it (def: -1 = the prologue, else the node index) and the last node that
+    // reads it; after the node list is complete the slots are packed by liveness (pack_slots below): the output of node n takes
+    // the place of a map of the same size whose last reader is a node <= n.  fp32 sessions need it (maps of 16 KB), bf16
+    // sessions just use less LDS.
     struct Slot { int off, h, w; };
+    struct SlotLife { int off, elems, def, last; };
     std::map<std::pair<int, int>, Slot> slot;          // (tensor, 0 as stored / 1 pooled to half size) -> LDS slot
+    std::vector<SlotLife> life;
     int top = 0;                                        // elements
-    auto new_slot = [&](int t, int form, int h, int w) { Slot sl{top, h, w}; top += ((h * w * C + 7) & ~7); slot[{t, form}] = sl; return sl; };
+    auto new_slot = [&](int t, int form, int h, int w, int def) {
+      Slot sl{top, h, w}; const int elems = (h * w * C + 7) & ~7;
+      life.push_back({top, elems, def, def}); top += elems; slot[{t, form}] = sl; return sl;
+    };
+    auto touch = [&](int off, int node) { for (SlotLife& l : life) if (l.off == off) l.last = std::max(l.last, node); };
     std::vector<ChainExt> exts; std::vector<int> ext_t, ext_store_t;
     std::vector<ChainNode> nodes; std::vector<int> node_out_t;
     auto pool_pad_of = [&](int n) { int pb, pa; same_pad(n, 3, 2, &pb, &pa); return pb; };
@@ -803,7 +815,7 @@ struct Planner {
       ChainExt x; memset(&x, 0, sizeof x);
       x.sh = td.H; x.sw = td.W; x.kind = pooled ? SRC_DOWN : SRC_SAME;
       x.h = pooled ? (td.H + 1) / 2 : td.H; x.w = pooled ? (td.W + 1) / 2 : td.W; x.pool_pad = pool_pad_of(td.H);
-      x.off = new_slot(store_t >= 0 ? store_t : t, store_t >= 0 ? 0 : (pooled ? 1 : 0), x.h, x.w).off;
+      x.off = new_slot(store_t >= 0 ? store_t : t, store_t >= 0 ? 0 : (pooled ? 1 : 0), x.h, x.w, -1).off;
       exts.push_back(x); ext_t.push_back(t); ext_store_t.push_back(store_t);
     };
     // pools of cell 0
@@ -816,12 +828,13 @@ struct Planner {
         ChainNode nd; memset(&nd, 0, sizeof nd);
         nd.pool_only = 1; nd.nsrc = 1; nd.h = (in.h + 1) / 2; nd.w = (in.w + 1) / 2; nd.pool_pad = pool_pad_of(in.h);
         nd.src[0] = ChainSrc{in.off, SRC_DOWN, in.h, in.w, 1.f};
-        nd.out_off = new_slot(ps.out_t, 0, nd.h, nd.w).off; nd.widx = -1;
+        touch(in.off, (int)nodes.size());
+        nd.out_off = new_slot(ps.out_t, 0, nd.h, nd.w, (int)nodes.size()).off; nd.widx = -1;
         nodes.push_back(nd); node_out_t.push_back(ps.out_t);
       }
     }
-    const size_t es2 = 2, pad = 8;
-    const int wnode_bytes = (int)((size_t)10 * C * 4 + (size_t)C * (C + pad) * es2);
+    const size_t es2 = s->dtype ? 2 : 4, pad = s->dtype ? 8 : 4;
+    const int wnode_bytes = (int)((((size_t)10 * C * 4 + (size_t)C * (C + pad) * es2) + 1023) & ~(size_t)1023);   // whole KB: streamed by LDS-DMA, 1 KB per wave instruction
     std::vector<unsigned char> blob;
     double bytes = 0, flops = 0, wbytes = 0;
     int nconv = 0, hw_max = 0;
@@ -831,6 +844,7 @@ struct Planner {
       ChainNode nd; memset(&nd, 0, sizeof nd);
       nd.nsrc = sp.nsrc; nd.h = hw; nd.w = hw; nd.widx = nconv++;
       hw_max = std::max(hw_max, hw);
+      const int me = (int)nodes.size();
       for (int j = 0; j < sp.nsrc; j++) {
         const int t = sp.src[j];
         const TensorDesc& td = s->tensors[t];
@@ -848,10 +862,11 @@ struct Planner {
           const Slot sl = slot[{t, 0}];
           nd.src[j] = ChainSrc{sl.off, sp.kind[j], sl.h, sl.w, sp.fw[j]};
         }
+        touch(nd.src[j].off, me);
       }
-      nd.out_off = new_slot(sp.out_t, 0, hw, hw).off;
+      nd.out_off = new_slot(sp.out_t, 0, hw, hw, me).off;
       nodes.push_back(nd); node_out_t.push_back(sp.out_t);
-      // weights in the kernel's LDS layout
+      // weights in the kernel's LDS layout: [9][C] depthwise f32 | [C] bias f32 | [C][C + pad] pointwise rows in the session dtype
       const PackTensor* wd = get(sp.key + ".depthwise_conv.conv.weight", {C, 1, 3, 3});
       const PackTensor* wp = get(sp.key + ".pointwise_conv.conv.weight", {C, C, 1, 1});
       const PackTensor* bp = get(sp.key + ".pointwise_conv.conv.bias", {C});
@@ -862,20 +877,53 @@ struct Planner {
       float* fdw = reinterpret_cast<float*>(blob.data() + base);
       for (int c = 0; c < C; c++) for (int t9 = 0; t9 < 9; t9++) fdw[(size_t)t9 * C + c] = wd->data[(size_t)c * 9 + t9];
       float* fb = fdw + 9 * C;
-      uint16_t* fw = reinterpret_cast<uint16_t*>(fb + C);
+      uint16_t* fw16 = reinterpret_cast<uint16_t*>(fb + C);
+      float* fw32 = fb + C;
       for (int n = 0; n < C; n++) {
         fb[n] = bp->data[n] * bn.scale[n] + bn.shift[n];
-        for (int k = 0; k < C; k++) fw[(size_t)n * (C + pad) + k] = f32_to_bf16(wp->data[(size_t)n * C + k] * bn.scale[n]);
+        for (int k = 0; k < C; k++) {
+          const float v = wp->data[(size_t)n * C + k] * bn.scale[n];
+          if (s->dtype) fw16[(size_t)n * (C + pad) + k] = f32_to_bf16(v); else fw32[(size_t)n * (C + pad) + k] = v;
+        }
       }
       bytes += (double)hw * hw * C * es(); flops += 2.0 * hw * hw * C * (9 + C); wbytes += (double)C * C * es() + 10.0 * C * 4;
     }
     if (nodes.size() > CH_MAX_NODES || exts.size() > CH_MAX_EXT) return false;
+    // ---- pack the slots by liveness: exact-size reuse (the maps of a chain come in three sizes).  A convolution node reads its
+    //      sources in its gather phase, two barriers before its MFMA phase writes the output, so its output may take the slot of
+    //      one of its own sources; a pool-only node reads and writes in one phase and may not. ----
+    {
+      std::vector<int> order(life.size());
+      for (size_t i = 0; i < life.size(); i++) order[i] = (int)i;
+      std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return life[x].def < life[y].def; });
+      struct Placed { int new_off, elems, last; };
+      std::vector<Placed> placed; std::map<int, int> remap; int ntop = 0;
+      for (int i : order) {
+        const SlotLife& l = life[i];
+        int pick = -1;
+        // (a pool-only node writes its output in its only phase, with no barrier behind the previous node's copy-out: it never
+        //  takes over a slot)
+        if (l.def >= 0 && !nodes[l.def].pool_only)
+          for (size_t q = 0; q < placed.size(); q++)
+            if (placed[q].elems == l.elems && placed[q].last <= l.def) { pick = (int)q; break; }
+        if (pick >= 0) { remap[l.off] = placed[pick].new_off; placed[pick].last = std::max(l.last, l.def); }
+        else { remap[l.off] = ntop; placed.push_back({ntop, l.elems, std::max(l.last, l.def)}); ntop += l.elems; }
+      }
+      for (ChainExt& x : exts) x.off = remap[x.off];
+      for (ChainNode& nd : nodes) { nd.out_off = remap[nd.out_off]; for (int j = 0; j < nd.nsrc; j++) nd.src[j].off = remap[nd.src[j].off]; }
+      top = ntop;
+    }
     ChainArgs ca; memset(&ca, 0, sizeof ca);
-    ca.nnodes = (int)nodes.size(); ca.nconv = nconv; ca.next = (int)exts.size(); ca.C = C; ca.wnode_bytes = wnode_bytes;
+    ca.nnodes = (int)nodes.size(); ca.nconv = nconv; ca.next = (int)exts.size(); ca.C = C; ca.wnode_bytes = wnode_bytes; ca.bf16 = s->dtype ? 1 : 0;
+    const size_t halo_b = (((size_t)(hw_max + 2) * (hw_max + 2) * (C + pad) * es2 + 15) & ~(size_t)15);
+    const size_t atile_b = (size_t)((hw_max * hw_max + 15) & ~15) * (C + pad) * es2;
     ca.off_w = ((size_t)top * es2 + 15) & ~(size_t)15;
-    ca.off_halo = ca.off_w + (size_t)nconv * wnode_bytes;
-    ca.off_atile = ca.off_halo + (((size_t)(hw_max + 2) * (hw_max + 2) * (C + pad) * es2 + 15) & ~(size_t)15);
-    ca.lds_bytes = ca.off_atile + (size_t)((hw_max * hw_max + 15) & ~15) * (C + pad) * es2;
+    // all node weights resident when they fit; else two nodes' weights in LDS, the next node's streamed under the running one (fp32)
+    ca.stream_w = (ca.off_w + (size_t)nconv * wnode_bytes + halo_b + atile_b > 158 * 1024) ? 1 : 0;
+    if (const char* e = getenv("HEP_CHAIN_STREAM")) ca.stream_w = atoi(e) != 0;                          // A/B knob, parity test of the streamed form in bf16
+    ca.off_halo = ca.off_w + (size_t)(ca.stream_w ? std::min(2, nconv) : nconv) * wnode_bytes;
+    ca.off_atile = ca.off_halo + halo_b;
+    ca.lds_bytes = ca.off_atile + atile_b;
     if (ca.lds_bytes > 158 * 1024) return false;
     const int op = new_op(OP_CHAIN, name);
     Op& o = s->ops[op];
@@ -938,7 +986,7 @@ int build_session(Session* s, const Pack& pack, std::string* err) {
     } else {
     const int op = P.new_op(OP_STEM, "stem");
     Op& o = s->ops[op];
-    o.stem.H = S; o.stem.W = S; o.stem.Ho = H; o.stem.Wo = W; o.stem.Cout = A.stem; o.stem.pad_t = pt; o.stem.pad_l = pl; o.stem.bf16 = s->dtype;
+    o.stem.H = S; o.stem.W = S; o.stem.Ho = H; o.stem.Wo = W; o.stem.Cout = A.stem; o.stem.pad_t = pt; o.stem.pad_l = pl; o.stem.bf16 = s->dtype; o.stem.mfma = stem_uses_mfma(A.stem);
     P.wref(op, F_STEM_W, P.wb.put_f32(wf)); P.wref(op, F_STEM_B, P.wb.put_f32(bn.shift));
     P.tref(op, F_STEM_OUT, x, true);
     o.act_bytes_per_image = 3.0 * S * S * 4 + (double)H * W * A.stem * P.es();
@@ -961,7 +1009,7 @@ int build_session(Session* s, const Pack& pack, std::string* err) {
   std::vector<Planner::SegSpec> pending; std::vector<std::string> pending_names;   // small-level BiFPN nodes awaiting a chain launch
   std::vector<Planner::PoolSpec> pending_pools;                                      // cell 0's two max-pools ride in the first chain
   // HEP_CHAIN: 0 = every node its own launch, 1 = chains inside k_sep.hip (mode 2), 2 (default) = LDS-resident chains
-  // (k_chain.hip) wherever they fit - bf16 / fp8 sessions at BiFPN width 64 - and k_sep.hip chains elsewhere
+  // (k_chain.hip) wherever they fit - BiFPN width 64 in every session dtype (fp32: streamed node weights) - and k_sep.hip chains elsewhere
   const int chain_mode = getenv("HEP_CHAIN") ? atoi(getenv("HEP_CHAIN")) : 2;
   for (int r = 0; r < A.fpn_cells; r++) {
     const std::string p = "bifpn." + std::to_string(r);

@@ -1,4 +1,4 @@
-// k_chain.hip - the small pyramid levels of a BiFPN cell boundary as ONE LDS-resident chain per image (bf16 sessions).
+// k_chain.hip - the small pyramid levels of a BiFPN cell boundary as ONE LDS-resident chain per image (bf16 and fp32 sessions).
 //
 // Between two visits of the 16x16 / 32x32 levels a BiFPN walks up to five nodes on maps of 8x8, 4x4 and 2x2 pixels
 // (reference efficientdet/model.py:212-264: p5_out -> p6_out -> p7_out -> next cell's p6_up -> p5_up; in cell 0
@@ -15,8 +15,16 @@
 //   2. runs the nodes out of LDS: gathers read LDS map slots (external inputs or earlier nodes' outputs), results are
 //      written to their slot and streamed to global memory without waiting (later launches read them from there);
 //   3. three workgroup barriers per node, no global round trip until the kernel ends.
-// Arithmetic, rounding points and operation order are those of sep_kernel (k_sep.hip), so the bf16 stage-parity tests
-// gate it like every other BiFPN node.  Widths other than what fits in LDS (and fp32 sessions) keep the k_sep.hip path.
+// Arithmetic, rounding points and operation order are those of sep_kernel (k_sep.hip), so the stage-parity tests
+// gate it like every other BiFPN node.  Widths other than what fits in LDS keep the k_sep.hip path.
+//
+// fp32 sessions (round 4): maps and weights are twice the bytes, so (a) the map slots are shared by liveness (host:
+// Planner::add_chain - a node's output takes the slot of a map nobody reads any more) and (b) the node weights are STREAMED
+// (template parameter): LDS holds two nodes' weights; the next node's are requested at the head of a node by LDS-DMA
+// (global_load_lds_dwordx4, 1 KB per wave instruction, no registers) into the buffer the previous node has left.  The chains of
+// an fp32 session ran as sep_kernel<false, 2> before: 35 us per five-node chain against 20 us here in bf16.
+#include <type_traits>
+
 #include "hep_dev.h"
 #include "hep_internal.h"
 
@@ -35,37 +43,69 @@ __device__ unsigned long long* g_chain_trace = nullptr;
 
 namespace {
 
-typedef bf16_t T;
-constexpr int PAD = 8, KSTEP = 32, KLANE = 8;
+// 8 consecutive channels as they lie in memory: 16 bytes (bf16) or two 16-byte vectors (fp32)
+template <bool BF16> struct Raw8;
+template <> struct Raw8<true> {
+  u32x4 v;
+  static __device__ __forceinline__ Raw8 load(const void* p) { Raw8 r; r.v = *reinterpret_cast<const u32x4*>(p); return r; }
+  __device__ __forceinline__ void store(void* p) const { *reinterpret_cast<u32x4*>(p) = v; }
+  __device__ __forceinline__ void zero() { v = (u32x4){0, 0, 0, 0}; }
+  __device__ __forceinline__ void unpack(float o[8]) const {
+#pragma unroll
+    for (int i = 0; i < 4; i++) { o[2 * i] = __uint_as_float(v[i] << 16); o[2 * i + 1] = __uint_as_float(v[i] & 0xffff0000u); }
+  }
+};
+template <> struct Raw8<false> {
+  f32x4 a, b;
+  static __device__ __forceinline__ Raw8 load(const void* p) { Raw8 r; r.a = reinterpret_cast<const f32x4*>(p)[0]; r.b = reinterpret_cast<const f32x4*>(p)[1]; return r; }
+  __device__ __forceinline__ void store(void* p) const { reinterpret_cast<f32x4*>(p)[0] = a; reinterpret_cast<f32x4*>(p)[1] = b; }
+  __device__ __forceinline__ void zero() { a = (f32x4){0.f, 0.f, 0.f, 0.f}; b = a; }
+  __device__ __forceinline__ void unpack(float o[8]) const {
+#pragma unroll
+    for (int i = 0; i < 4; i++) { o[i] = a[i]; o[4 + i] = b[i]; }
+  }
+};
 
 // 8 channels of a map slot at pixel (y, x) as floats; zero outside the map (SAME padding of the pool / the depthwise halo).
 // The load is unconditional (clamped address) and the zero is a select: conditional loads would each sit in a basic
 // block of their own and serialise into one memory round trip per tap.
-__device__ __forceinline__ u32x4 slot_raw(const T* slot, int h, int w, int C, int y, int x, int c0) {
+template <bool BF16, typename T> __device__ __forceinline__ Raw8<BF16> slot_raw(const T* slot, int h, int w, int C, int y, int x, int c0) {
   const bool ok = y >= 0 && y < h && x >= 0 && x < w;
   const int yc = min(max(y, 0), h - 1), xc = min(max(x, 0), w - 1);
-  u32x4 r = *reinterpret_cast<const u32x4*>(slot + (int64_t)(yc * w + xc) * C + c0);
-  if (!ok) r = (u32x4){0, 0, 0, 0};
+  Raw8<BF16> r = Raw8<BF16>::load(slot + (int64_t)(yc * w + xc) * C + c0);
+  if (!ok) r.zero();
   return r;
 }
-__device__ __forceinline__ void unpack8(u32x4 r, float v[8]) {
-#pragma unroll
-  for (int i = 0; i < 4; i++) { v[2 * i] = __uint_as_float(r[i] << 16); v[2 * i + 1] = __uint_as_float(r[i] & 0xffff0000u); }
-}
-__device__ __forceinline__ void slot_load(const T* slot, int h, int w, int C, int y, int x, int c0, float v[8]) {
-  unpack8(slot_raw(slot, h, w, C, y, x, c0), v);
+template <bool BF16, typename T> __device__ __forceinline__ void slot_load(const T* slot, int h, int w, int C, int y, int x, int c0, float v[8]) {
+  slot_raw<BF16>(slot, h, w, C, y, x, c0).unpack(v);
 }
 
 // zero-padded 3x3 stride-2 max-pool of a slot at output pixel (y, x) (utils_extra.py:72-86: the pad value takes part);
 // all nine loads are in flight before the first is consumed
-__device__ __forceinline__ void slot_pool(const T* slot, int h, int w, int C, int pad, int y, int x, int c0, float m[8]) {
-  u32x4 raw[9];
+// (fp32: two passes of four channels - nine 32-byte vectors in flight per lane spilled)
+__device__ __forceinline__ void slot_pool4(const float* slot, int h, int w, int C, int pad, int y, int x, int c0, float* m) {
+  f32x4 raw[9];
 #pragma unroll
-  for (int q = 0; q < 9; q++) raw[q] = slot_raw(slot, h, w, C, 2 * y - pad + q / 3, 2 * x - pad + q % 3, c0);
+  for (int q = 0; q < 9; q++) {
+    const int yy = 2 * y - pad + q / 3, xx = 2 * x - pad + q % 3;
+    const bool ok = yy >= 0 && yy < h && xx >= 0 && xx < w;
+    raw[q] = *reinterpret_cast<const f32x4*>(slot + (int64_t)(min(max(yy, 0), h - 1) * w + min(max(xx, 0), w - 1)) * C + c0);
+    if (!ok) raw[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int q = 0; q < 9; q++)
+#pragma unroll
+    for (int c = 0; c < 4; c++) m[c] = q == 0 ? raw[q][c] : fmaxf(m[c], raw[q][c]);
+}
+template <bool BF16, typename T> __device__ __forceinline__ void slot_pool(const T* slot, int h, int w, int C, int pad, int y, int x, int c0, float m[8]) {
+  if constexpr (!BF16) { slot_pool4(slot, h, w, C, pad, y, x, c0, m); slot_pool4(slot, h, w, C, pad, y, x, c0 + 4, m + 4); return; }
+  Raw8<BF16> raw[9];
+#pragma unroll
+  for (int q = 0; q < 9; q++) raw[q] = slot_raw<BF16>(slot, h, w, C, 2 * y - pad + q / 3, 2 * x - pad + q % 3, c0);
 #pragma unroll
   for (int q = 0; q < 9; q++) {
     float v[8];
-    unpack8(raw[q], v);
+    raw[q].unpack(v);
 #pragma unroll
     for (int c = 0; c < 8; c++) m[c] = q == 0 ? v[c] : fmaxf(m[c], v[c]);
   }
@@ -73,7 +113,13 @@ __device__ __forceinline__ void slot_pool(const T* slot, int h, int w, int C, in
 
 }  // namespace
 
+template <bool BF16, bool STREAM>
 __global__ __launch_bounds__(CHAIN_THREADS) void chain_kernel(ChainArgs a) {
+  typedef Vec8<BF16> V;
+  typedef typename V::elem T;
+  typedef Raw8<BF16> R8;
+  typedef typename std::conditional<BF16, u32x4, f32x4>::type frag_t;
+  constexpr int PAD = BF16 ? 8 : 4, KSTEP = BF16 ? 32 : 16, KLANE = BF16 ? 8 : 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   HEP_POISON(smem, a.lds_bytes);
   T* slots = reinterpret_cast<T*>(smem);
@@ -96,18 +142,19 @@ __global__ __launch_bounds__(CHAIN_THREADS) void chain_kernel(ChainArgs a) {
     // the chain's weights: one contiguous blob already in the LDS layout (per node [9*C] f32 depthwise | [C] f32 bias |
     // [C][C+PAD] bf16 pointwise rows)
     constexpr int WB = 4096 / CHAIN_THREADS;
-    const int wvecs = (int)(((size_t)a.nconv * a.wnode_bytes) >> 4);
+    const int wvecs = (int)(((size_t)(STREAM ? 1 : a.nconv) * a.wnode_bytes) >> 4);
     u32x4 wv[WB];
 #pragma unroll
     for (int j = 0; j < WB; j++) { const int i = tid + j * CHAIN_THREADS; if (i < wvecs) wv[j] = reinterpret_cast<const u32x4*>(a.wblob)[i]; }
     // external maps that are copied as they are (their own resolution)
-    u32x4 ev[CH_MAX_EXT];
+    constexpr int EPF = BF16 ? CH_MAX_EXT : 4;          // maps whose first row of vectors is prefetched (fp32: 8 registers each)
+    R8 ev[EPF];
 #pragma unroll
-    for (int e = 0; e < CH_MAX_EXT; e++) {
+    for (int e = 0; e < EPF; e++) {
       const ChainExt& x = a.ext[e];
-      ev[e] = (u32x4){0, 0, 0, 0};
+      ev[e].zero();
       if (e < a.next && x.kind != SRC_DOWN && cg < CG && prow < x.h * x.w)
-        ev[e] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(x.src) + ((int64_t)b * x.sh * x.sw + prow) * C + cg * 8);
+        ev[e] = R8::load(reinterpret_cast<const T*>(x.src) + ((int64_t)b * x.sh * x.sw + prow) * C + cg * 8);
     }
 #pragma unroll
     for (int j = 0; j < WB; j++) { const int i = tid + j * CHAIN_THREADS; if (i < wvecs) reinterpret_cast<u32x4*>(wreg)[i] = wv[j]; }
@@ -119,18 +166,14 @@ __global__ __launch_bounds__(CHAIN_THREADS) void chain_kernel(ChainArgs a) {
       T* dst = slots + x.off;
       const T* src = reinterpret_cast<const T*>(x.src) + (int64_t)b * x.sh * x.sw * C;
       if (x.kind != SRC_DOWN) {
-        if (prow < x.h * x.w) *reinterpret_cast<u32x4*>(dst + (int64_t)prow * C + cg * 8) = ev[e];
-        for (int p = prow + pstride; p < x.h * x.w; p += pstride)
-          *reinterpret_cast<u32x4*>(dst + (int64_t)p * C + cg * 8) = *reinterpret_cast<const u32x4*>(src + (int64_t)p * C + cg * 8);
+        if (e < EPF && prow < x.h * x.w) ev[e < EPF ? e : 0].store(dst + (int64_t)prow * C + cg * 8);
+        for (int p = prow + (e < EPF ? pstride : 0); p < x.h * x.w; p += pstride) R8::load(src + (int64_t)p * C + cg * 8).store(dst + (int64_t)p * C + cg * 8);
       } else {       // pooled while it is loaded (zero-padded 3x3 / 2 max-pool); optionally also a map of its own (p6_in)
         for (int p = prow; p < x.h * x.w; p += pstride) {
           float m[8];
-          slot_pool(src, x.sh, x.sw, C, x.pool_pad, p / x.w, p % x.w, cg * 8, m);
-          u32x4 raw;
-#pragma unroll
-          for (int q = 0; q < 4; q++) raw[q] = pack_bf16x2(m[2 * q], m[2 * q + 1]);      // exact: the values are bf16 already
-          *reinterpret_cast<u32x4*>(dst + (int64_t)p * C + cg * 8) = raw;
-          if (x.store) *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(x.store) + ((int64_t)b * x.h * x.w + p) * C + cg * 8) = raw;
+          slot_pool<BF16>(src, x.sh, x.sw, C, x.pool_pad, p / x.w, p % x.w, cg * 8, m);
+          V::store(dst, (int64_t)p * C + cg * 8, m);                                    // exact: the values are session-dtype numbers already
+          if (x.store) V::store(x.store, ((int64_t)b * x.h * x.w + p) * C + cg * 8, m);
         }
       }
     }
@@ -165,16 +208,28 @@ __global__ __launch_bounds__(CHAIN_THREADS) void chain_kernel(ChainArgs a) {
         for (int p = prow; p < hw; p += pstride) {
           float m[8];
           const int py = (int)__umulhi((uint32_t)p, w_rcp);
-          slot_pool(slots + s0.off, s0.sh, s0.sw, C, nd.pool_pad, py, p - py * w, cg * 8, m);
-          Vec8<true>::store(oslot, (int64_t)p * C + cg * 8, m);
-          Vec8<true>::store(nd.out, ((int64_t)b * hw + p) * C + cg * 8, m);
+          slot_pool<BF16>(slots + s0.off, s0.sh, s0.sw, C, nd.pool_pad, py, p - py * w, cg * 8, m);
+          V::store(oslot, (int64_t)p * C + cg * 8, m);
+          V::store(nd.out, ((int64_t)b * hw + p) * C + cg * 8, m);
         }
       __syncthreads();
       continue;
     }
-    const float* wdw_s = reinterpret_cast<const float*>(wreg + (size_t)nd.widx * a.wnode_bytes);
+    const float* wdw_s = reinterpret_cast<const float*>(wreg + (size_t)(STREAM ? (nd.widx & 1) : nd.widx) * a.wnode_bytes);
     const float* bias_s = wdw_s + 9 * C;
     const T* wpw_s = reinterpret_cast<const T*>(bias_s + C);
+    // streamed weights: the NEXT node's go straight from global memory into the other LDS buffer (LDS-DMA, no registers: held in
+    // registers under the node they spilled); that buffer was last read by the previous node, which every wave has left
+    // (its closing barrier).  1 KB per wave instruction; the host pads a node's weights to whole KB.
+    if constexpr (STREAM) {
+      if (nd.widx + 1 < a.nconv) {
+        const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(a.wblob) + (size_t)(nd.widx + 1) * a.wnode_bytes;
+        unsigned char* wdst = wreg + (size_t)((nd.widx + 1) & 1) * a.wnode_bytes;
+        for (int c = wave; c * 1024 < a.wnode_bytes; c += CHAIN_WAVES)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + c * 1024 + lane * 16),
+                                           (__attribute__((address_space(3))) void*)(wdst + c * 1024), 16, 0, 0);
+      }
+    }
     const int HS = w + 2;
     // fused + swished input with its one-pixel zero halo
     if (cg < CG)
@@ -188,18 +243,19 @@ __global__ __launch_bounds__(CHAIN_THREADS) void chain_kernel(ChainArgs a) {
             if (i >= nd.nsrc) break;
             const ChainSrc& s = nd.src[i];
             float t[8];
-            if (s.kind == SRC_DOWN) slot_pool(slots + s.off, s.sh, s.sw, C, nd.pool_pad, y, x, cg * 8, t);
-            else if (s.kind == SRC_UP) slot_load(slots + s.off, s.sh, s.sw, C, y >> 1, x >> 1, cg * 8, t);
-            else slot_load(slots + s.off, s.sh, s.sw, C, y, x, cg * 8, t);
+            if (s.kind == SRC_DOWN) slot_pool<BF16>(slots + s.off, s.sh, s.sw, C, nd.pool_pad, y, x, cg * 8, t);
+            else if (s.kind == SRC_UP) slot_load<BF16>(slots + s.off, s.sh, s.sw, C, y >> 1, x >> 1, cg * 8, t);
+            else slot_load<BF16>(slots + s.off, s.sh, s.sw, C, y, x, cg * 8, t);
 #pragma unroll
             for (int c = 0; c < 8; c++) v[c] = fmaf(s.fw, t[c], v[c]);
           }
 #pragma unroll
-          for (int c = 0; c < 8; c++) v[c] = swish_t<true>(v[c]);
+          for (int c = 0; c < 8; c++) v[c] = swish_t<BF16>(v[c]);
         }
-        Vec8<true>::store(halo, (int64_t)pos * CH + cg * 8, v);
+        V::store(halo, (int64_t)pos * CH + cg * 8, v);
       }
     CSTAMP();
+    if constexpr (STREAM) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's share of the node's weights (requested one node ago) has landed
     __syncthreads();
     CSTAMP();
     // depthwise 3x3 -> MFMA operand tile [pixels][C]; rows beyond the map are zeroed (their products are discarded)
@@ -211,14 +267,14 @@ __global__ __launch_bounds__(CHAIN_THREADS) void chain_kernel(ChainArgs a) {
 #pragma unroll
           for (int q = 0; q < 9; q++) {
             float hv[8];
-            Vec8<true>::load(halo, (int64_t)((py + q / 3) * HS + px + q % 3) * CH + cg * 8, hv);
+            V::load(halo, (int64_t)((py + q / 3) * HS + px + q % 3) * CH + cg * 8, hv);
             const f32x4* wp = reinterpret_cast<const f32x4*>(wdw_s + q * C + cg * 8);
             const f32x4 w0 = wp[0], w1 = wp[1];
 #pragma unroll
             for (int c = 0; c < 4; c++) { acc[c] = fmaf(hv[c], w0[c], acc[c]); acc[4 + c] = fmaf(hv[4 + c], w1[c], acc[4 + c]); }
           }
         }
-        Vec8<true>::store(atile, (int64_t)p * CH + cg * 8, acc);
+        V::store(atile, (int64_t)p * CH + cg * 8, acc);
       }
     CSTAMP();
     __syncthreads();
@@ -233,9 +289,13 @@ __global__ __launch_bounds__(CHAIN_THREADS) void chain_kernel(ChainArgs a) {
       const T* arow = atile + (int64_t)m * CH + KLANE * g;
       f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
       for (int ks = 0; ks < ksteps; ks++) {
-        u32x4 wf = {}, xa = {};
-        if (ks * KSTEP + KLANE * g < C) { wf = *reinterpret_cast<const u32x4*>(wrow + ks * KSTEP); xa = *reinterpret_cast<const u32x4*>(arow + ks * KSTEP); }
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf), __builtin_bit_cast(bf16x8, xa), acc, 0, 0, 0);
+        frag_t wf = {}, xa = {};
+        if (ks * KSTEP + KLANE * g < C) { wf = *reinterpret_cast<const frag_t*>(wrow + ks * KSTEP); xa = *reinterpret_cast<const frag_t*>(arow + ks * KSTEP); }
+        if constexpr (BF16) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf), __builtin_bit_cast(bf16x8, xa), acc, 0, 0, 0);
+        else {
+#pragma unroll
+          for (int q = 0; q < 4; q++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[q], xa[q], acc, 0, 0, 0);      // exact fp32; lane group g supplies k = 16 ks + 4 g + q
+        }
       }
       const int nn = nt * 16 + 4 * g;
       if (m < hw && nn < C) {
@@ -243,7 +303,7 @@ __global__ __launch_bounds__(CHAIN_THREADS) void chain_kernel(ChainArgs a) {
         float v[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) v[q] = acc[q] + bias[q];
-        Vec8<true>::store4(oslot, (int64_t)m * C + nn, v);
+        V::store4(oslot, (int64_t)m * C + nn, v);
       }
     }
     CSTAMP();
@@ -251,8 +311,7 @@ __global__ __launch_bounds__(CHAIN_THREADS) void chain_kernel(ChainArgs a) {
     CSTAMP();
     // the finished map leaves as full 16-byte vectors; nobody in this launch reads it from global memory
     if (cg < CG)
-      for (int p = prow; p < hw; p += pstride)
-        *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(nd.out) + ((int64_t)b * hw + p) * C + cg * 8) = *reinterpret_cast<const u32x4*>(oslot + (int64_t)p * C + cg * 8);
+      for (int p = prow; p < hw; p += pstride) R8::load(oslot + (int64_t)p * C + cg * 8).store(reinterpret_cast<T*>(nd.out) + ((int64_t)b * hw + p) * C + cg * 8);
     CSTAMP();
   }
 #ifdef HEP_MBF_TRACE
@@ -271,12 +330,19 @@ extern "C" int hep_dbg_chain_trace(unsigned long long* host, int nblocks, int en
 }
 #endif
 
-int chain_prepare(void) {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024) == hipSuccess ? 0 : -1;
+template <bool BF16, bool STREAM> static int chain_prep_one() {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel<BF16, STREAM>), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024) == hipSuccess ? 0 : -1;
 }
+int chain_prepare(void) { return chain_prep_one<true, false>() | chain_prep_one<true, true>() | chain_prep_one<false, false>() | chain_prep_one<false, true>(); }
 
 void launch_chain(const ChainArgs& a_, hipStream_t s) {
   ChainArgs a = a_;
   a.nt_rcp = rcp_u32((uint32_t)((a.C + 15) >> 4));
-  hipLaunchKernelGGL(chain_kernel, dim3(a.B), dim3(CHAIN_THREADS), a.lds_bytes, s, a);
+  if (a.bf16) {
+    if (a.stream_w) hipLaunchKernelGGL((chain_kernel<true, true>), dim3(a.B), dim3(CHAIN_THREADS), a.lds_bytes, s, a);
+    else hipLaunchKernelGGL((chain_kernel<true, false>), dim3(a.B), dim3(CHAIN_THREADS), a.lds_bytes, s, a);
+  } else {
+    if (a.stream_w) hipLaunchKernelGGL((chain_kernel<false, true>), dim3(a.B), dim3(CHAIN_THREADS), a.lds_bytes, s, a);
+    else hipLaunchKernelGGL((chain_kernel<false, false>), dim3(a.B), dim3(CHAIN_THREADS), a.lds_bytes, s, a);
+  }
 }

@@ -204,21 +204,23 @@ __global__ __launch_bounds__(256) void stem_valu_kernel(StemArgs a) {
   }
 }
 
-int stem_uses_mfma(int cout) { static const char* force = getenv("HEP_STEM_MFMA"); return force ? atoi(force) != 0 : cout > 32; }
+// (read at every call - plan naming and launch - never cached: a session created after the environment changed gets the plan it asked for;
+//  stems wider than 64 channels have no MFMA instantiation and keep the VALU form)
+int stem_uses_mfma(int cout) { const char* force = getenv("HEP_STEM_MFMA"); return cout <= 64 && (force ? atoi(force) != 0 : cout > 32); }
 
 void launch_stem(const StemArgs& a_, hipStream_t s) {
   StemArgs a = a_;
   // Measured (b16 / b8, stand-alone): phi 0 (32 channels) bf16 MFMA 18.5-19.7 us, VALU 14.5 us; fp32 22.2 / 20.2 us;
   // phi 3 (40 channels, 512 x 512) MFMA 34.1 us, VALU 46.8 us.  The MFMA form's four-byte gathers cost what its matrix
   // pipe saves on the narrow stem; it wins once the VALU form needs a fifth channel group.  HEP_STEM_MFMA=0|1 overrides.
-  if (!stem_uses_mfma(a.Cout)) {
+  if (!a.mfma) {
     dim3 grid((unsigned)((a.Wo + 63) / 64), (unsigned)((a.Ho + 3) / 4), (unsigned)a.B);
     if (a.bf16) hipLaunchKernelGGL(stem_valu_kernel<true>, grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(stem_valu_kernel<false>, grid, dim3(256), 0, s, a);
     return;
   }
   const int TX = (a.Wo + 15) >> 4, total = a.B * a.Ho * TX;
-  static const int mpw_env = getenv("HEP_STEM_MPW") ? atoi(getenv("HEP_STEM_MPW")) : 0;
+  const char* mpw_e = getenv("HEP_STEM_MPW"); const int mpw_env = mpw_e ? atoi(mpw_e) : 0;
   a.mpw = mpw_env > 0 ? mpw_env : 2;                     // m-tiles per wave (measured 1 / 2 / 3 / 4 / 8: 21.2 / 18.5 / 21.4 / 19.7 / 26.1 us at phi 0)
   a.tx_rcp = rcp_u32((uint32_t)TX); a.ho_rcp = rcp_u32((uint32_t)a.Ho);
   dim3 grid((unsigned)((total + 4 * a.mpw - 1) / (4 * a.mpw)));

@@ -34,6 +34,9 @@
 
 #pragma once
 #include <type_traits>
+#ifndef HEP_PW_UF32
+#define HEP_PW_UF32 2
+#endif
 
 template <bool BF16> struct Frag;
 template <> struct Frag<true> { typedef u32x4 raw; static constexpr int KSTEP = 32, KLANE = 8; };
@@ -92,7 +95,8 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
   else if (MODE == 1) { m0 = mblk * (16 * MT); ntile0 = nchunk * 4 * NT + wave * NT; }
   else {
     m0 = mblk * (16 * MT); ntile0 = nchunk * NT;
-    const int steps = (K + F::KSTEP - 1) / F::KSTEP, per = ((steps + 3) / 4 + 1) & ~1;   // even: slices start on whole load batches
+    constexpr int UU = BF16 ? 2 : HEP_PW_UF32;
+    const int steps = (K + F::KSTEP - 1) / F::KSTEP, per = ((steps + 3) / 4 + UU - 1) / UU * UU;   // slices start on whole load batches
     kbeg = min(K, wave * per * F::KSTEP); kend = min(K, (wave + 1) * per * F::KSTEP);
   }
 
@@ -134,7 +138,10 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
   // one CU gets out of L2, and a deeper ring changed nothing.  With both halves requested back to back the second one
   // merges with the miss in flight.  One batch stays in flight behind the one being multiplied (two slots); the first
   // does not depend on the squeeze-excite scale and is issued before its prologue.
-  constexpr int U = MODE == 0 ? 1 : 2, KS2 = U * F::KSTEP;
+  // fp32 sessions (HEP_PW_UF32): four k-steps per batch - the same 64 k per batch as bf16 - measured SLOWER than two (round 4:
+  // 1152 -> 192 project conv 17.7 us against 16.2 us): the fp32 K loop is not twice the round trips of the bf16 one, it is twice
+  // the bytes through one CU's L1 at the same ~40 GB/s plus the exact-fp32 MFMAs (128 MAC per clock and CU) in series with them
+  constexpr int U = MODE == 0 ? 1 : (BF16 ? 2 : HEP_PW_UF32), KS2 = U * F::KSTEP;
   Step<PREC, MT, NT> st[2][U];
   auto load2 = [&](int slot, int kk) {
 #pragma unroll

@@ -439,7 +439,7 @@ extern "C" int hep_dbg_tower_trace(unsigned long long* host, int max_waves, int 
 
 void launch_tower(const SepArgs& a, hipStream_t s) {
   // images per workgroup: amortises the weight staging; keep >= ~1000 workgroups in the launch
-  static const int ipb_env = getenv("HEP_TOWER_IPB") ? atoi(getenv("HEP_TOWER_IPB")) : 0;
+  const char* ipb_e = getenv("HEP_TOWER_IPB"); const int ipb_env = ipb_e ? atoi(ipb_e) : 0;
   int ipb = ipb_env > 0 ? ipb_env : 1;
   if (ipb_env <= 0) while (ipb < 4 && (int64_t)a.total_tiles * ((a.B + 2 * ipb - 1) / (2 * ipb)) >= 900) ipb *= 2;
   ipb = std::min(ipb, a.B);

@@ -522,9 +522,10 @@ static void launch_xbf_n(const XbfArgs& a, dim3 grid, hipStream_t s) {
   else if (a.NT1 == 2) hipLaunchKernelGGL((xbf_kernel<BF16, KS, S, TOH, TOW, 2, 0, 0>), grid, dim3(XT), a.lds_bytes, s, a);
   else hipLaunchKernelGGL((xbf_kernel<BF16, KS, S, TOH, TOW, 3, 0, 0>), grid, dim3(XT), a.lds_bytes, s, a);
 }
+int xbf_generic_forced(void) { const char* e = getenv("HEP_XBF_GENERIC"); return e && atoi(e) != 0 ? 1 : 0; }
 template <bool BF16>
 static void launch_xbf_t(const XbfArgs& a, dim3 grid, hipStream_t s) {
-  static const bool generic = getenv("HEP_XBF_GENERIC") && atoi(getenv("HEP_XBF_GENERIC")) != 0;     // A/B switch, parity test of the generic path
+  const bool generic = a.generic != 0;           // A/B switch, parity test of the generic path (decided when the plan is built)
 #define X(k_, s_, th, tw, n1, k1, n2) \
   if (!generic && a.k == k_ && a.s == s_ && a.NT1 == n1 && a.K1 == k1 && a.NT2 == n2) { hipLaunchKernelGGL((xbf_kernel<BF16, k_, s_, th, tw, n1, k1, n2>), grid, dim3(XT), a.lds_bytes, s, a); return; }
   XBF_SPECS(X)
@@ -535,6 +536,7 @@ static void launch_xbf_t(const XbfArgs& a, dim3 grid, hipStream_t s) {
   else launch_xbf_n<BF16, 5, 2, 8, 8>(a, grid, s);
 }
 int xbf_specialised(const XbfArgs& a) {
+  if (a.generic) return 0;
 #define X(k_, s_, th, tw, n1, k1, n2) if (a.k == k_ && a.s == s_ && a.NT1 == n1 && a.K1 == k1 && a.NT2 == n2) return 1;
   XBF_SPECS(X)
 #undef X

@@ -414,20 +414,60 @@ def test_module_dropin_and_pipeline(api):
         assert np.array_equal(got.numpy(), want)
 
 
-@pytest.mark.parametrize("env", [{"HEP_MBF": "all"}, {"HEP_MBF_TS": "8"}, {"HEP_MBF": "none", "HEP_DWLDS": "0"}, {"HEP_DWLDS": "1", "HEP_MBF": "none"},
-                                 {"HEP_LANES": "2"}, {"HEP_CHAIN": "0"}, {"HEP_CHAIN": "1"}, {"HEP_SE_MAXMB": "0"}, {"HEP_SE_MAXMB": "1000"}, {"HEP_PWG": "0", "HEP_PW_MT2": "0"}, {"HEP_TOWER": "0"},
-                                 {"HEP_XBF": "0"}, {"HEP_XBF_GENERIC": "1"}, {"HEP_XBF_TPW": "3"}, {"HEP_XBF_MINH": "32"}, {"HEP_SBF": "1"}, {"HEP_STEM_MFMA": "1"}])
-def test_alternative_plans_keep_parity(api, env, monkeypatch):
+def _plan_syms(s, batch):
+    return [(name, sym) for name, _b, _f, sym in s.kernels(batch)]
+
+
+# every alternative plan: the environment that selects it and a predicate over the session's launch list (name, device
+# function) that is true ONLY when the alternative really was planned - the knobs are read when a session is created
+# (csrc/hep_model.cpp reads them with a plain getenv), so a case that silently re-tested the default plan would fail here
+ALT_PLANS = [
+    ({"HEP_MBF": "all"}, lambda ks: any(n == "b3.front" for n, _ in ks) and any(n == "b0.front" for n, _ in ks)),
+    ({"HEP_MBF_TS": "8"}, lambda ks: not any("mbf_kernel" in y and y.endswith(", 16>") for _, y in ks)),
+    ({"HEP_MBF": "none", "HEP_DWLDS": "0"}, lambda ks: not any("mbf_kernel" in y for _, y in ks)),
+    ({"HEP_DWLDS": "1", "HEP_MBF": "none"}, lambda ks: all(n.endswith(".dw") for n, y in ks if "mbf_kernel" in y) and any("mbf_kernel" in y for _, y in ks)),
+    ({"HEP_LANES": "2"}, None),
+    ({"HEP_CHAIN": "0"}, lambda ks: not any("chain_kernel" in y or "sep_kernel<false, 2" in y for _, y in ks)),
+    ({"HEP_CHAIN": "1"}, lambda ks: any("sep_kernel<false, 2" in y for _, y in ks) and not any("chain_kernel" in y for _, y in ks)),
+    ({"HEP_CHAIN_F32": "0"}, lambda ks: any("sep_kernel<false, 2" in y for _, y in ks) and not any("chain_kernel" in y for _, y in ks)),
+    ({"HEP_SE_MAXMB": "0"}, lambda ks: sum("se_finish_kernel" in y for _, y in ks) >= 12),
+    ({"HEP_SE_MAXMB": "1000"}, lambda ks: not any("se_finish_kernel" in y for _, y in ks)),
+    ({"HEP_PWG": "0", "HEP_PW_MT2": "0"}, lambda ks: not any("pw_group_kernel" in y for _, y in ks)),
+    ({"HEP_TOWER": "0"}, lambda ks: not any("tower_kernel" in y for _, y in ks)),
+    ({"HEP_XBF": "0"}, lambda ks: not any("xbf_kernel" in y for _, y in ks)),
+    ({"HEP_XBF_GENERIC": "1"}, lambda ks: any("xbf_kernel" in y for _, y in ks) and all(y.endswith(", 0, 0>") for _, y in ks if "xbf_kernel" in y)),
+    ({"HEP_XBF_TPW": "3"}, None),
+    ({"HEP_XBF_MINH": "32"}, "bf16:xbf>=4"),          # (fp32 tiles of the 32x32 boundary do not fit LDS: the plan change is checked on a bf16 session)
+    ({"HEP_SBF": "1"}, lambda ks: any("sbf_kernel" in y for _, y in ks)),
+    ({"HEP_STEM_MFMA": "1"}, lambda ks: any(y.startswith("stem_kernel<") for _, y in ks)),
+    ({"HEP_PW_NT2": "4"}, None),                       # (changes the tile only from batch 16 up)
+]
+
+
+@pytest.mark.parametrize("env,planned", ALT_PLANS, ids=["-".join(f"{k}={v}" for k, v in e.items()) for e, _ in ALT_PLANS])
+def test_alternative_plans_keep_parity(api, env, planned, monkeypatch):
     """The planner picks between implementations by measurement (fused MBConv front vs expand+depthwise,
     tower kernel vs tiled sepconv for the heads, node chains, LDS depthwise, batch lanes); every alternative
-    must produce the same numbers."""
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
+    must produce the same numbers - and must really be the plan that ran (``planned``)."""
     phi, size, batch = 0, 256, 3
     sd = api["sd"](phi, 4)
+    s0 = api["Session"](sd, phi, size, batch, "fp32")
+    default_plan = _plan_syms(s0, batch)
+    s0.close()
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
     x = torch.from_numpy(seeded_input((batch, 3, size, size), 21))
     ref = api["R"].forward(sd, x, phi)
     s = api["Session"](sd, phi, size, batch, "fp32")
+    plan = _plan_syms(s, batch)
+    if planned == "bf16:xbf>=4":
+        sb = api["Session"](sd, phi, size, batch, "bf16")
+        nx = sum("xbf_kernel" in y for _, y in _plan_syms(sb, batch))
+        sb.close()
+        assert nx >= 4, f"{env}: {nx} boundary launches in the bf16 plan"
+    elif planned is not None:
+        assert planned(plan), f"{env}: the alternative was not planned: {plan}"
+        assert plan != default_plan, f"{env}: same launch list as the default plan"
     out = s.forward(x.cuda())
     torch.cuda.synchronize()
     for name, a, b in zip(("regression", "classification", "rotation", "translation_raw", "hand"), out[1:], ref[1:]):
@@ -438,11 +478,20 @@ def test_alternative_plans_keep_parity(api, env, monkeypatch):
     s.close()
 
 
-@pytest.mark.parametrize("phi,env", [(1, {"HEP_SEP_WLDS": "0"}), (3, {"HEP_SEP_WLDS": "0"})])
+def test_default_fp32_plan_runs_its_chains_in_lds(api):
+    """fp32 sessions at BiFPN width 64 run the small-level node chains on chain_kernel<false, true> (weights streamed by LDS-DMA),
+    not on the k_sep.hip fallback."""
+    s = api["Session"](api["sd"](0, 4), 0, 256, 2, "fp32")
+    syms = [y for _, y in _plan_syms(s, 2)]
+    s.close()
+    assert sum(y.startswith("chain_kernel<false") for y in syms) == 4 and "chain_kernel<false, true>" in syms and not any("sep_kernel<false, 2" in y for y in syms), syms
+
+
+@pytest.mark.parametrize("phi,env", [(1, {"HEP_SEP_WLDS": "0"}), (3, {"HEP_SEP_WLDS": "0"}), (0, {"HEP_CHAIN_STREAM": "1"})])
 def test_bf16_plan_variants_are_bit_identical(api, phi, env, monkeypatch):
     """A plan choice that only moves data differently - BiFPN nodes wider than 64 channels with their pointwise weights staged
-    in LDS or fetched per fragment (widths 88 and 160) - leaves the arithmetic and its order alone: bf16 sessions must agree
-    bit for bit."""
+    in LDS or fetched per fragment (widths 88 and 160), LDS-resident node chains with all node weights resident or streamed by
+    LDS-DMA (width 64) - leaves the arithmetic and its order alone: bf16 sessions must agree bit for bit."""
     size, batch = 256, 2
     sd = api["sd"](phi, 5)
     x = torch.from_numpy(seeded_input((batch, 3, size, size), 23)).cuda()

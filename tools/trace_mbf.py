@@ -5,7 +5,7 @@ _capi.LIB_PATH = os.path.join(os.path.dirname(_capi.LIB_PATH), "libhep_trace.so"
 from hmd_ego_pose_amd.model import Session
 from hmd_ego_pose_amd.weights import seeded_state_dict
 B=int(sys.argv[1]); nblocks=int(sys.argv[2])
-s = Session(seeded_state_dict(0,0), 0, 256, B, "bf16")   # HEP_MBF_TRACE_SEL="Cexp,H" picks the layer
+s = Session(seeded_state_dict(0,0), 0, 256, B, sys.argv[3] if len(sys.argv) > 3 else "bf16")   # HEP_MBF_TRACE_SEL="Cexp,H" picks the layer
 x = torch.randn(B,3,256,256, device="cuda")
 for _ in range(3): s.forward(x, want_features=False)
 torch.cuda.synchronize()

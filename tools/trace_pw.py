@@ -10,7 +10,7 @@ B = int(sys.argv[1]); nblocks = int(sys.argv[2])
 l = _capi.lib()
 f = l.hep_dbg_pw_trace; f.restype = ctypes.c_int; f.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
 f(None, 0, 1)                                     # before the session: the plan's graph captures the buffer pointer
-s = Session(seeded_state_dict(0, 0), 0, 256, B, "bf16")
+s = Session(seeded_state_dict(0, 0), 0, 256, B, sys.argv[3] if len(sys.argv) > 3 else "bf16")
 x = torch.randn(B, 3, 256, 256, device="cuda")
 for _ in range(3): s.forward(x, want_features=False)
 torch.cuda.synchronize()
