@@ -139,13 +139,16 @@ def add_vs_ref(phi, size, precisions=("fp32", "bf16", "fp8")):
 
 def pmc_traffic(symbol, tag=""):
     """HBM bytes per launch of `symbol` from the newest committed PMC pass of this configuration
-    (profiles/r*/*_pmc_per_kernel.json for the default workload, *_phi3_pmc_per_kernel.json for phi 3 @ 512 b8:
+    (profiles/r*/*_pmc_per_kernel.json for the default workload, *_phi3_pmc_per_kernel.json for phi 3 @ 512 b8, *_fp32_pmc_per_kernel.json for fp32 sessions:
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, KB per launch).  gfx950 correction from
     /opt/skills/guides/MI355X_MICROARCH.md: FETCH_SIZE counts 128-byte requests as 64 bytes, so reads are
     doubled; WRITE_SIZE is exact for 16-byte stores.  None when no pass holds the kernel."""
     import glob
+    def tag_of(path):
+        b = os.path.basename(path)
+        return "phi3_" if b.endswith("_phi3_pmc_per_kernel.json") else ("fp32_" if b.endswith("_fp32_pmc_per_kernel.json") else "")
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "*_pmc_per_kernel.json")), reverse=True):
-        if (tag == "phi3_") != os.path.basename(f).endswith("_phi3_pmc_per_kernel.json"):
+        if tag_of(f) != tag:
             continue
         try:
             d = json.load(open(f))
@@ -157,6 +160,48 @@ def pmc_traffic(symbol, tag=""):
         except (OSError, KeyError, ValueError):
             continue
     return None
+
+
+def launch_profile(sess, B, ms_step, ms_one_batch, traffic_of=None, layers=True):
+    """Per-launch durations of one session (one batch in flight: the only regime in which a launch can be timed alone) and the
+    roofline block built from them.  Durations come from an eager pass with a HIP event in front of every launch; the event
+    pairs add a constant to each launch, calibrated live: the same launches replayed as one hipGraph (no events) take
+    total_ms, so the per-launch overhead is (sum(eager) - total_ms) / n."""
+    total_ms, per = sess.profile(B, 20, per_kernel=True)
+    ks = sess.kernels(B)
+    ev_overhead = max(0.0, (sum(per) - total_ms) / len(per))
+    per = [max(t - ev_overhead, 1e-6) for t in per]
+    agg = {}
+    for (name, nbytes, flops, sym), t in zip(ks, per):
+        a = agg.setdefault(sym, [0.0, 0.0, 0.0, 0])
+        a[0] += t; a[1] += nbytes; a[2] += flops; a[3] += 1
+    sym, (t, nbytes, flops, calls) = max(agg.items(), key=lambda kv: kv[1][0])
+    achieved = nbytes / (t * 1e-3) / 1e9
+    step_bytes = sum(k[1] for k in ks)
+    fracs = sorted(k[1] / (t_ * 1e-3) / 1e9 / HBM_PEAK_GBS for k, t_ in zip(ks, per))
+    out = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+           "traffic": traffic_of(sym) if traffic_of else None,
+           "kernel": sym, "launches_per_step": calls, "avg_launch_us": round(t / calls * 1e3, 2),
+           "algorithmic_bytes_per_launch": round(nbytes / calls), "share_of_step": round(t / sum(per), 3),
+           "measured_with_batches_in_flight": 1,
+           "graph_replay_ms": round(total_ms, 4), "event_overhead_us_subtracted": round(ev_overhead * 1e3, 2),
+           # the north-star target is ">= 0.60 of the per-layer roofline": how many launches are there, and where the step is as a whole
+           "layers_total": len(ks), "layers_at_or_above_0p6": sum(f >= 0.6 for f in fracs),
+           "best_layer_frac": round(fracs[-1], 4), "median_layer_frac": round(fracs[len(fracs) // 2], 4),
+           "time_weighted_frac": round(step_bytes / (sum(per) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+           "whole_step_algorithmic_GBps": round(step_bytes / (ms_step * 1e-3) / 1e9, 1),
+           "end_to_end_frac": round(step_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+           "end_to_end_frac_one_batch": round(step_bytes / (ms_one_batch * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    # context: the next device functions by total time, same definitions
+    out["top"] = [{"kernel": k, "launches_per_step": v[3], "avg_launch_us": round(v[0] / v[3] * 1e3, 2), "share_of_step": round(v[0] / sum(per), 3),
+                   "achieved": round(v[1] / (v[0] * 1e-3) / 1e9, 1), "frac": round(v[1] / (v[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                  for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:5]]
+    if layers:
+        # every launch, stand-alone in sequence: name, device function, us, algorithmic MB, GB/s, fraction of 8 TB/s
+        out["layers"] = [[name, sym_, round(t_ * 1e3, 2), round(nb / 1e6, 3), round(nb / (t_ * 1e-3) / 1e9, 1), round(nb / (t_ * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)]
+                         for (name, nb, _fl, sym_), t_ in zip(ks, per)]
+        out["layers_columns"] = ["launch", "device_function", "us", "algorithmic_MB", "GB/s", "frac_of_8TB/s"]
+    return out
 
 
 def parse_args(argv=None):
@@ -182,13 +227,40 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
+def visible_gpu_count():
+    """GPUs this process would see, WITHOUT initialising HIP (the supervising parent of a --gpus N run must never do that:
+    it forks N rank processes next).  Counts the KFD topology nodes that have SIMDs (/sys/class/kfd: CPUs are nodes with
+    simd_count 0) and applies HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES; None when the topology cannot be read (the
+    ranks then check for themselves before the rendezvous)."""
+    import glob
+    n = 0
+    files = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not files:
+        return None
+    for f in files:
+        try:
+            for line in open(f):
+                k, _, v = line.partition(" ")
+                if k == "simd_count" and int(v) > 0:
+                    n += 1
+        except (OSError, ValueError):
+            return None
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([t for t in v.split(",") if t.strip() != ""]))
+    return n
+
+
 def self_launch(args):
     """--gpus N without a torchrun environment: start N rank processes of this script (one per GPU, env as
     torchrun sets it), supervise them and relay rank 0's line.  This parent never initialises a GPU and never
     exec()s.  A rank that dies takes the others with it (they would otherwise sit in the rendezvous / a barrier
     until the collective time-out)."""
-    import torch
-    ndev = torch.cuda.device_count()          # (does not initialise HIP on this image)
+    ndev = visible_gpu_count()                # sysfs only: nothing here may initialise HIP / HSA before the ranks are forked
+    if ndev is None:                          # no KFD topology at all (a host without the amdgpu driver): torch's own count
+        import torch
+        ndev = torch.cuda.device_count()
     if not args.single_device and ndev < args.gpus:
         sys.stderr.write(f"bench.py: --gpus {args.gpus} but only {ndev} GPU(s) visible\n")
         return 2
@@ -249,9 +321,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     B, S, phi = args.batch, args.size, args.phi
     if world > 1:
-        import torch.distributed as td
-        sys.stderr.write(f"bench.py rank {rank}/{td.get_world_size()}: device cuda:{local_rank} ({torch.cuda.get_device_name(local_rank)}), "
-                         f"backend {td.get_backend()}\n")
+        sys.stderr.write("bench.py " + hd.describe(local_rank) + "\n"); sys.stderr.flush()      # before the first collective (the weight broadcast below)
 
     # weights: synthetic (no checkpoint ships with the reference), rank 0's copy broadcast once over RCCL
     sd = hd.broadcast_state_dict(seeded_state_dict(phi, 0), dev)
@@ -333,6 +403,8 @@ def main():
         CD = max(1, min(args.comm_depth, D))          # batches in flight in the serving loop (slot i % CD: own session, own stream)
         cstreams = [torch.cuda.Stream(dev) for _ in range(CD)]
 
+        hd.warm_up_p2p(dev)       # RCCL sets its point-to-point communicators up lazily: not inside the timed loop
+
         def serve_loop(sessions, steps):
             got = [None] * CD
             views = [s_.output_views() for s_ in sessions]      # the handles' own head buffers: the forward below copies nothing
@@ -381,7 +453,8 @@ def main():
             comm = {"value": round(G * k2 / e2, 2), "unit": "frames/s", "ms_per_step": round(e2 / k2 * 1e3, 4), "steps": k2, "batches_in_flight": CD,
                     "what": f"{CD} batches in flight per GPU (slot i % {CD}: own session and stream): scatter uint8 frames from rank 0 (point to point) -> preprocess -> forward -> decode -> "
                             f"filter (score > {args.comm_score_threshold}, NMS 0.5, top {M}) -> gather detection rows on rank 0; classifier header bias shifted by "
-                            f"{-float(qt.item()):.3f} so that ~{args.comm_candidates:g} anchors per frame pass the threshold (a trained network's rate)",
+                            f"{-float(qt.item()):.3f} so that ~{args.comm_candidates:g} anchors per frame pass the threshold (a trained network's rate) - "
+                            f"this bias-shifted session is a LOAD knob, not the parity-tested weight set (every other tensor and the arithmetic are the same; `pathological` runs the unshifted, parity-tested weights)",
                     "scatter_bytes_per_step": int((G - B) * S * S * 3), "gather_bytes_per_step": int((G - B) * row_bytes),
                     "backend": args.backend if world > 1 else None, "ranks": world,
                     "mean_detections_per_frame": round(float(got["count"].float().mean()), 1),
@@ -414,44 +487,12 @@ def main():
             out["one_batch_in_flight"] = {"value": round(B * k1 / e1, 2), "ms_per_step": round(e1 / k1 * 1e3, 4), "steps": k1}
             if comm is not None:
                 comm["vs_one_batch_in_flight"] = round(comm["value"] / out["one_batch_in_flight"]["value"], 3)
-            # per-launch durations: one batch in flight (the only regime in which a launch can be timed alone;
-            # with several batches in flight launches of different batches overlap on the chip)
+            # per-launch durations and the roofline block (launch_profile above)
             s0 = main_loop.sess[0]
-            total_ms, per = s0.profile(B, 20, per_kernel=True)
+            cfg = (phi, S, B, args.precision)
+            traffic_of = (lambda y: pmc_traffic(y)) if cfg == (0, 256, 16, "bf16") else ((lambda y: pmc_traffic(y, "phi3_")) if cfg == (3, 512, 8, "bf16") else ((lambda y: pmc_traffic(y, "fp32_")) if cfg == (0, 256, 16, "fp32") else None))
+            out["roofline"] = launch_profile(s0, B, ms, e1 / k1 * 1e3, traffic_of, layers=not args.no_layers)
             torch.cuda.synchronize(dev)
-            ks = s0.kernels(B)
-            # per-launch durations come from an eager pass with a HIP event in front of every launch; the
-            # event pairs add a constant to each launch.  Calibrate it live: the same launches replayed as one
-            # hipGraph (no events) take total_ms, so the per-launch overhead is (sum(eager) - total_ms) / n.
-            ev_overhead = max(0.0, (sum(per) - total_ms) / len(per))
-            per = [max(t - ev_overhead, 1e-6) for t in per]
-            agg = {}
-            for (name, nbytes, flops, sym), t in zip(ks, per):
-                a = agg.setdefault(sym, [0.0, 0.0, 0.0, 0])
-                a[0] += t; a[1] += nbytes; a[2] += flops; a[3] += 1
-            sym, (t, nbytes, flops, calls) = max(agg.items(), key=lambda kv: kv[1][0])
-            achieved = nbytes / (t * 1e-3) / 1e9
-            step_bytes = sum(k[1] for k in ks)
-            out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(achieved / HBM_PEAK_GBS, 4),
-                               "traffic": pmc_traffic(sym) if (phi, S, B, args.precision) == (0, 256, 16, "bf16") else (pmc_traffic(sym, "phi3_") if (phi, S, B, args.precision) == (3, 512, 8, "bf16") else None),
-                               "kernel": sym, "launches_per_step": calls, "avg_launch_us": round(t / calls * 1e3, 2),
-                               "algorithmic_bytes_per_launch": round(nbytes / calls), "share_of_step": round(t / sum(per), 3),
-                               "measured_with_batches_in_flight": 1,
-                               "graph_replay_ms": round(total_ms, 4), "event_overhead_us_subtracted": round(ev_overhead * 1e3, 2),
-                               "whole_step_algorithmic_GBps": round(step_bytes / (ms * 1e-3) / 1e9, 1),
-                               "end_to_end_frac": round(step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                               "end_to_end_frac_one_batch": round(step_bytes / (e1 / k1) / 1e9 / HBM_PEAK_GBS, 4)}
-            # context for the block above: the next device functions by total time, same definitions
-            out["roofline"]["top"] = [
-                {"kernel": k, "launches_per_step": v[3], "avg_launch_us": round(v[0] / v[3] * 1e3, 2), "share_of_step": round(v[0] / sum(per), 3),
-                 "achieved": round(v[1] / (v[0] * 1e-3) / 1e9, 1), "frac": round(v[1] / (v[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-                for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:5]]
-            if not args.no_layers:
-                # every launch, stand-alone in sequence: name, device function, us, algorithmic MB, GB/s, fraction of 8 TB/s
-                out["roofline"]["layers"] = [[name, sym_, round(t_ * 1e3, 2), round(nb / 1e6, 3), round(nb / (t_ * 1e-3) / 1e9, 1), round(nb / (t_ * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)]
-                                             for (name, nb, _fl, sym_), t_ in zip(ks, per)]
-                out["roofline"]["layers_columns"] = ["launch", "device_function", "us", "algorithmic_MB", "GB/s", "frac_of_8TB/s"]
             if not args.no_fp32 and args.precision != "fp32":
                 # the precision that meets the 0.1 mm ADD bound on the seeded weights (add_vs_ref below): same loops, fp32 sessions
                 main_loop.close()
@@ -462,11 +503,26 @@ def main():
                 ef1 = f32.timed(k1, 1)
                 out["fp32"] = {"value": round(B * args.steps / ef, 2), "ms_per_step": round(ef / args.steps * 1e3, 4),
                                "one_batch_in_flight": {"value": round(B * k1 / ef1, 2), "ms_per_step": round(ef1 / k1 * 1e3, 4)},
-                               "what": "the same step and loops with fp32 sessions (fp32 storage, exact-fp32 MFMA): the only precision within 0.1 mm ADD of the reference on the seeded weights"}
+                               "what": "the same step and loops with fp32 sessions (fp32 storage, exact-fp32 MFMA): the only precision within 0.1 mm ADD of the reference on the seeded weights",
+                               "roofline": launch_profile(f32.sess[0], B, ef / args.steps * 1e3, ef1 / k1 * 1e3,
+                                                          (lambda y: pmc_traffic(y, "fp32_")) if (phi, S, B) == (0, 256, 16) else None, layers=not args.no_layers)}
                 f32.close()
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(phi, S)
                 out["add_vs_ref"] = add_vs_ref(phi, S)
+                # ONE number that satisfies both halves of the metric (frames/s AND ADD(-S) within 0.1 mm of the reference): the
+                # fastest measured precision among those inside the bound
+                cands = {args.precision: (out["value"], out["one_batch_in_flight"]["value"])}
+                if "fp32" in out:
+                    cands["fp32"] = (out["fp32"]["value"], out["fp32"]["one_batch_in_flight"]["value"])
+                ok = [p for p in out["add_vs_ref"]["meets_bound"] if p in cands]
+                if ok:
+                    best = max(ok, key=lambda p: cands[p][0])
+                    out["meets_add_bound"] = {"dtype": best, "value": cands[best][0], "unit": "frames/s", "one_batch_in_flight": cands[best][1],
+                                              "add_mm": out["add_vs_ref"][best]["add_mm"], "add_s_mm": out["add_vs_ref"][best]["add_s_mm"], "bound_mm": 0.1,
+                                              "what": f"frames/s of the {best} sessions ({D} batches in flight) - the fastest measured precision whose pose stays within 0.1 mm ADD of the reference's"}
+                else:
+                    out["meets_add_bound"] = None
         print(json.dumps(out), flush=True)
     main_loop.close()
     if world > 1:

@@ -24,6 +24,20 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 
 static const int kOutK[5] = {4, 1, 3, 3, 63};
 
+// Nothing may leave an entry point as a C++ exception (include/hep.h: "never throws"; the C# host P/Invokes these symbols, and
+// ONNXRuntime - the library this one replaces - reports failures through its API, Program.cs:59-61).  Every extern "C" function
+// is a function-try-block ending in one of these handlers: std::bad_alloc / length_error from a hostile weight pack, a vector
+// that outgrew memory, anything else -> HEP_ERR_INTERNAL and a message in hep_last_error().
+static int hep_caught() noexcept {
+  try { throw; }
+  catch (const std::bad_alloc&) { try { g_err = "out of host memory (std::bad_alloc)"; } catch (...) {} }
+  catch (const std::exception& e) { try { g_err = std::string("internal error: ") + e.what(); } catch (...) {} }
+  catch (...) { try { g_err = "internal error: unknown C++ exception"; } catch (...) {} }
+  return HEP_ERR_INTERNAL;
+}
+#define HEP_CATCH_INT catch (...) { return hep_caught(); }
+#define HEP_CATCH_VOID catch (...) { hep_caught(); }
+
 namespace hep {
 
 Session::~Session() {
@@ -35,6 +49,7 @@ Session::~Session() {
   for (hipStream_t st : lane_streams) hipStreamDestroy(st);
   for (hipEvent_t ev : lane_events) hipEventDestroy(ev);
   if (fork_event) hipEventDestroy(fork_event);
+  if (pre_event) hipEventDestroy(pre_event);
   hipFree(d_weights); hipFree(d_arena); hipFree(d_pre[0]); hipFree(d_pre[1]);
   for (int i = 0; i < 5; i++) { hipFree(d_out[i]); hipFree(d_feat_nchw[i]); }
   hipFree(d_in); hipFree(d_anchors); hipFree(d_tanchors); hipFree(d_boxes); hipFree(d_trans); hipFree(d_cam);
@@ -182,14 +197,14 @@ extern "C" {
 int hep_abi_version(void) { return HEP_ABI_VERSION; }
 const char* hep_last_error(void) { return g_err.c_str(); }
 
-int hep_device_count(void) {
+int hep_device_count(void) try {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   return n;
-}
+} HEP_CATCH_INT
 
 int hep_create_from_memory(const void* pack, size_t pack_bytes, int phi, int size, int max_batch, int dtype, int device,
-                           unsigned flags, hep_handle** out) {
+                           unsigned flags, hep_handle** out) try {
   if (!out) return fail(HEP_ERR_INVALID, "out is NULL");
   *out = nullptr;
   if (!pack || pack_bytes < 12) return fail(HEP_ERR_PACK, "weight pack: empty");
@@ -226,9 +241,9 @@ int hep_create_from_memory(const void* pack, size_t pack_bytes, int phi, int siz
   if (dtype == HEP_FP8) if (int rc2 = calibrate_fp8(s)) return rc2;
   *out = h.release();
   return 0;
-}
+} HEP_CATCH_INT
 
-int hep_create(const char* pack_path, int phi, int size, int max_batch, int dtype, int device, unsigned flags, hep_handle** out) {
+int hep_create(const char* pack_path, int phi, int size, int max_batch, int dtype, int device, unsigned flags, hep_handle** out) try {
   if (out) *out = nullptr;
   if (!pack_path) return fail(HEP_ERR_INVALID, "pack_path is NULL");
   std::ifstream f(pack_path, std::ios::binary | std::ios::ate);
@@ -238,9 +253,9 @@ int hep_create(const char* pack_path, int phi, int size, int max_batch, int dtyp
   std::vector<char> buf((size_t)n);
   if (!f.read(buf.data(), n)) return fail(HEP_ERR_PACK, "cannot read weight pack");
   return hep_create_from_memory(buf.data(), buf.size(), phi, size, max_batch, dtype, device, flags, out);
-}
+} HEP_CATCH_INT
 
-void hep_destroy(hep_handle* h) {
+void hep_destroy(hep_handle* h) try {
   if (!h) return;
   hipSetDevice(h->s.device);
   hipDeviceSynchronize();
@@ -263,23 +278,23 @@ void hep_destroy(hep_handle* h) {
   }
 #endif
   delete h;
-}
+} HEP_CATCH_VOID
 
-int hep_num_anchors(const hep_handle* h) { return h ? h->s.num_anchors : fail(HEP_ERR_INVALID, "handle is NULL"); }
+int hep_num_anchors(const hep_handle* h) try { return h ? h->s.num_anchors : fail(HEP_ERR_INVALID, "handle is NULL"); } HEP_CATCH_INT
 
-int hep_output_shape(const hep_handle* h, int index, int batch, int64_t dims[4], int* ndim) {
+int hep_output_shape(const hep_handle* h, int index, int batch, int64_t dims[4], int* ndim) try {
   if (!h || !dims || index < 0 || index >= HEP_NUM_OUTPUTS) return fail(HEP_ERR_INVALID, "bad argument");
   const Session& s = h->s;
   if (index < 5) { dims[0] = batch; dims[1] = s.arch.fpn_w; dims[2] = s.levels[index]; dims[3] = s.levels[index]; if (ndim) *ndim = 4; }
   else { dims[0] = batch; dims[1] = s.num_anchors; dims[2] = kOutK[index - 5]; dims[3] = 1; if (ndim) *ndim = 3; }
   return 0;
-}
+} HEP_CATCH_INT
 
-int hep_output_device(const hep_handle* h, int index, float** ptr) {
+int hep_output_device(const hep_handle* h, int index, float** ptr) try {
   if (!h || !ptr || index < 5 || index >= HEP_NUM_OUTPUTS) return fail(HEP_ERR_INVALID, "hep_output_device: index must be one of the five head outputs");
   *ptr = h->s.d_out[index - 5];
   return 0;
-}
+} HEP_CATCH_INT
 
 static int check_run(hep_handle* h, const void* input, int batch) {
   if (!h) return fail(HEP_ERR_INVALID, "handle is NULL");
@@ -310,7 +325,7 @@ static int export_feats(Session& s, int batch, float* const feats[5], bool devic
 }
 
 int hep_run_device(hep_handle* h, const float* input, const int64_t in_strides[4], int batch, float* const outs[5],
-                   float* const feats[5], void* stream) {
+                   float* const feats[5], void* stream) try {
   if (int rc = check_run(h, input, batch)) return rc;
   Session& s = h->s;
   std::lock_guard<std::mutex> lk(s.mu);
@@ -323,10 +338,10 @@ int hep_run_device(hep_handle* h, const float* input, const int64_t in_strides[4
       if (outs[i] && outs[i] != s.d_out[i])
         HIPRET(hipMemcpyAsync(outs[i], s.d_out[i], (size_t)batch * s.num_anchors * kOutK[i] * 4, hipMemcpyDeviceToDevice, st));
   return export_feats(s, batch, feats, true, st);
-}
+} HEP_CATCH_INT
 
 int hep_run(hep_handle* h, const float* input_nchw, int batch, float* const feats[5], float* regression, float* classification,
-            float* rotation, float* translation_raw, float* hand) {
+            float* rotation, float* translation_raw, float* hand) try {
   if (int rc = check_run(h, input_nchw, batch)) return rc;
   Session& s = h->s;
   std::lock_guard<std::mutex> lk(s.mu);
@@ -342,18 +357,18 @@ int hep_run(hep_handle* h, const float* input_nchw, int batch, float* const feat
   if (int rc = export_feats(s, batch, feats, false, s.stream)) return rc;
   HIPRET(hipStreamSynchronize(s.stream));
   return 0;
-}
+} HEP_CATCH_INT
 
-int hep_anchors(int size, float* anchors, float* translation_anchors) {
+int hep_anchors(int size, float* anchors, float* translation_anchors) try {
   if (size < 128 || size % 128 != 0) return fail(HEP_ERR_UNSUPPORTED, "size must be a positive multiple of 128");
   std::vector<float> a, t;
   const int n = host_anchors(size, anchors ? &a : nullptr, translation_anchors ? &t : nullptr);
   if (anchors) memcpy(anchors, a.data(), a.size() * 4);
   if (translation_anchors) memcpy(translation_anchors, t.data(), t.size() * 4);
   return n;
-}
+} HEP_CATCH_INT
 
-int hep_preprocess_u8_device(hep_handle* h, const uint8_t* rgb_hwc, int batch, int height, int width, float* out_hwc, void* stream) {
+int hep_preprocess_u8_device(hep_handle* h, const uint8_t* rgb_hwc, int batch, int height, int width, float* out_hwc, void* stream) try {
   if (!h || !rgb_hwc || !out_hwc || batch < 1 || height < 1 || width < 1) return fail(HEP_ERR_INVALID, "bad argument");
   Session& s = h->s;
   HIPRET(hipSetDevice(s.device));
@@ -371,20 +386,33 @@ int hep_preprocess_u8_device(hep_handle* h, const uint8_t* rgb_hwc, int batch, i
   launch_preprocess(a, (hipStream_t)stream);
   HIPRET(hipGetLastError());
   return 0;
-}
+} HEP_CATCH_INT
 
 int hep_preprocess_i420_device(hep_handle* h, const uint8_t* yuv, int batch, int height, int width, int crop, int resized,
-                               float* out_hwc, void* stream) {
+                               float* out_hwc, void* stream) try {
   if (!h || !yuv || !out_hwc || batch < 1) return fail(HEP_ERR_INVALID, "bad argument");
   if (height < 2 || width < 2 || (height & 1) || (width & 1)) return fail(HEP_ERR_INVALID, "4:2:0 frames have even sides");
   if (crop < 1 || crop > height || crop > width || resized < 1) return fail(HEP_ERR_INVALID, "crop must fit the frame, resized must be positive");
   Session& s = h->s;
   HIPRET(hipSetDevice(s.device));
   std::lock_guard<std::mutex> lk(s.mu);          // the two scratch buffers belong to the handle
-  const size_t need[2] = {(size_t)batch * crop * crop * 3, (size_t)batch * resized * resized * 3};
-  for (int i = 0; i < 2; i++)
-    if (s.pre_bytes[i] < need[i]) { hipFree(s.d_pre[i]); s.d_pre[i] = nullptr; s.pre_bytes[i] = 0; HIPRET(hipMalloc((void**)&s.d_pre[i], need[i])); s.pre_bytes[i] = need[i]; }
   hipStream_t st = (hipStream_t)stream;
+  // The scratch frames are used ASYNCHRONOUSLY on the caller's stream and the mutex only covers the enqueue: a second call on
+  // another stream (an in-flight pool) must not overwrite them while the first call's kernels still read them.  An event is
+  // recorded behind the last launch of every call and the next call's stream waits for it first (device-side, no host stall).
+  if (!s.pre_event) HIPRET(hipEventCreateWithFlags(&s.pre_event, hipEventDisableTiming));
+  // sized once for the handle's max_batch frames of this geometry; growing them (a larger geometry later) waits for the
+  // last user first - hipFree would stall every stream of the device anyway, so it is kept off the steady state
+  const int cap = batch > s.max_batch ? batch : s.max_batch;
+  const size_t need[2] = {(size_t)batch * crop * crop * 3, (size_t)batch * resized * resized * 3};
+  const size_t want[2] = {(size_t)cap * crop * crop * 3, (size_t)cap * resized * resized * 3};
+  for (int i = 0; i < 2; i++)
+    if (s.pre_bytes[i] < need[i]) {
+      if (s.pre_pending) { HIPRET(hipEventSynchronize(s.pre_event)); s.pre_pending = false; }
+      hipFree(s.d_pre[i]); s.d_pre[i] = nullptr; s.pre_bytes[i] = 0;
+      HIPRET(hipMalloc((void**)&s.d_pre[i], want[i])); s.pre_bytes[i] = want[i];
+    }
+  if (s.pre_pending) HIPRET(hipStreamWaitEvent(st, s.pre_event, 0));
   // Program.cs:161 cvtColor + 383-397 CenterCropAndRescaleMat
   Yv12Args ya; ya.in = yuv; ya.bgr = s.d_pre[0]; ya.B = batch; ya.H = height; ya.W = width; ya.crop = crop;
   ya.ow = (width - crop) / 2; ya.oh = (height - crop) / 2;
@@ -396,12 +424,13 @@ int hep_preprocess_i420_device(hep_handle* h, const uint8_t* yuv, int batch, int
   const float scale = (float)s.size / (float)resized;
   ResizeArgs r2; r2.in = s.d_pre[1]; r2.out = out_hwc; r2.B = batch; r2.H = resized; r2.W = resized; r2.S = s.size; r2.norm = 1;
   r2.nw = s.size; r2.nh = (int)((float)resized * scale);
-  if (r2.nh < 1 || r2.nh > s.size) return fail(HEP_ERR_UNSUPPORTED, "preprocess: resized frame does not fit the network size");
+  if (r2.nh < 1 || r2.nh > s.size) { hipEventRecord(s.pre_event, st); s.pre_pending = true; return fail(HEP_ERR_UNSUPPORTED, "preprocess: resized frame does not fit the network size"); }
   r2.inv_scale_x = (double)resized / r2.nw; r2.inv_scale_y = (double)resized / r2.nh;
   launch_resize_u8(r2, st);
   HIPRET(hipGetLastError());
+  HIPRET(hipEventRecord(s.pre_event, st)); s.pre_pending = true;
   return 0;
-}
+} HEP_CATCH_INT
 
 // ---- decode / filter ----
 // The *_locked helpers expect s.mu to be held; the device entry points take it around the launch, the host
@@ -421,14 +450,14 @@ static int decode_locked(Session& s, const float* regression, const float* trans
 }
 
 int hep_decode_device(hep_handle* h, const float* regression, const float* translation_raw, const float* camera, int batch,
-                      float* boxes, float* translation, void* stream) {
+                      float* boxes, float* translation, void* stream) try {
   if (!h || !camera || !boxes || !translation) return fail(HEP_ERR_INVALID, "bad argument");
   Session& s = h->s;
   if (batch < 1 || batch > s.max_batch) return fail(HEP_ERR_UNSUPPORTED, "batch outside 1..max_batch");
   std::lock_guard<std::mutex> lk(s.mu);
   HIPRET(hipSetDevice(s.device));
   return decode_locked(s, regression, translation_raw, camera, batch, boxes, translation, (hipStream_t)stream);
-}
+} HEP_CATCH_INT
 
 static int ensure_post(Session& s) {
   const size_t n = (size_t)s.max_batch * s.num_anchors;
@@ -448,7 +477,7 @@ static int ensure_stage(Session& s, int i) {
 }
 
 int hep_decode(hep_handle* h, const float* regression, const float* translation_raw, const float* camera, int batch,
-               float* boxes, float* translation) {
+               float* boxes, float* translation) try {
   if (!h || !camera || !boxes || !translation) return fail(HEP_ERR_INVALID, "bad argument");
   Session& s = h->s;
   if (batch < 1 || batch > s.max_batch) return fail(HEP_ERR_UNSUPPORTED, "batch outside 1..max_batch");
@@ -471,7 +500,7 @@ int hep_decode(hep_handle* h, const float* regression, const float* translation_
   HIPRET(hipMemcpyAsync(translation, s.d_trans, n * 12, hipMemcpyDeviceToHost, s.stream));
   HIPRET(hipStreamSynchronize(s.stream));
   return 0;
-}
+} HEP_CATCH_INT
 
 static int filter_locked(Session& s, const float* boxes, const float* classification, const float* rotation,
                          const float* translation, const float* hand, int batch, float score_threshold, float nms_threshold,
@@ -494,7 +523,7 @@ static int filter_locked(Session& s, const float* boxes, const float* classifica
 int hep_filter_device(hep_handle* h, const float* boxes, const float* classification, const float* rotation,
                       const float* translation, const float* hand, int batch, float score_threshold, float nms_threshold,
                       int max_detections, float* det_boxes, float* det_scores, int32_t* det_labels, float* det_rotation,
-                      float* det_translation, float* det_hand, int32_t* det_index, int32_t* det_count, void* stream) {
+                      float* det_translation, float* det_hand, int32_t* det_index, int32_t* det_count, void* stream) try {
   if (!h || !boxes || !det_count) return fail(HEP_ERR_INVALID, "bad argument");
   Session& s = h->s;
   if (batch < 1 || batch > s.max_batch) return fail(HEP_ERR_UNSUPPORTED, "batch outside 1..max_batch");
@@ -503,12 +532,12 @@ int hep_filter_device(hep_handle* h, const float* boxes, const float* classifica
   HIPRET(hipSetDevice(s.device));
   return filter_locked(s, boxes, classification, rotation, translation, hand, batch, score_threshold, nms_threshold, max_detections,
                        det_boxes, det_scores, det_labels, det_rotation, det_translation, det_hand, det_index, det_count, (hipStream_t)stream);
-}
+} HEP_CATCH_INT
 
 int hep_filter(hep_handle* h, const float* boxes, const float* classification, const float* rotation, const float* translation,
                const float* hand, int batch, float score_threshold, float nms_threshold, int max_detections, float* det_boxes,
                float* det_scores, int32_t* det_labels, float* det_rotation, float* det_translation, float* det_hand,
-               int32_t* det_index, int32_t* det_count) {
+               int32_t* det_index, int32_t* det_count) try {
   if (!h || !boxes || !classification || !rotation || !translation || !hand || !det_count) return fail(HEP_ERR_INVALID, "bad argument");
   Session& s = h->s;
   if (batch < 1 || batch > s.max_batch) return fail(HEP_ERR_UNSUPPORTED, "batch outside 1..max_batch");
@@ -541,11 +570,11 @@ int hep_filter(hep_handle* h, const float* boxes, const float* classification, c
   HIPRET(hipMemcpyAsync(det_count, ct_, (size_t)batch * 4, hipMemcpyDeviceToHost, s.stream));
   HIPRET(hipStreamSynchronize(s.stream));
   return 0;
-}
+} HEP_CATCH_INT
 
 // ---- pose errors (evaluator) ----
 int hep_pose_errors_device(const float* points, int num_points, const float* rvec_gt, const float* t_gt, const float* rvec_pred,
-                           const float* t_pred, int num_pairs, int max_points, double* add, double* add_s, void* stream) {
+                           const float* t_pred, int num_pairs, int max_points, double* add, double* add_s, void* stream) try {
   if (!points || !rvec_gt || !t_gt || !rvec_pred || !t_pred || !add || !add_s) return fail(HEP_ERR_INVALID, "bad argument");
   if (num_points < 1 || num_pairs < 0) return fail(HEP_ERR_INVALID, "num_points must be >= 1 and num_pairs >= 0");
   if (max_points < 1 || max_points > 1024) return fail(HEP_ERR_UNSUPPORTED, "max_points must be in 1..1024 (the reference uses 1000)");
@@ -555,10 +584,10 @@ int hep_pose_errors_device(const float* points, int num_points, const float* rve
   launch_pose_errors(a, (hipStream_t)stream);
   HIPRET(hipGetLastError());
   return 0;
-}
+} HEP_CATCH_INT
 
 int hep_pose_errors(int device, const float* points, int num_points, const float* rvec_gt, const float* t_gt, const float* rvec_pred,
-                    const float* t_pred, int num_pairs, int max_points, double* add, double* add_s) {
+                    const float* t_pred, int num_pairs, int max_points, double* add, double* add_s) try {
   if (!points || !rvec_gt || !t_gt || !rvec_pred || !t_pred || !add || !add_s) return fail(HEP_ERR_INVALID, "bad argument");
   if (num_points < 1 || num_pairs < 0) return fail(HEP_ERR_INVALID, "num_points must be >= 1 and num_pairs >= 0");
   if (num_pairs == 0) return 0;
@@ -579,13 +608,13 @@ int hep_pose_errors(int device, const float* points, int num_points, const float
   HIPRET(hipMemcpy(add, d_add, ob, hipMemcpyDeviceToHost));
   HIPRET(hipMemcpy(add_s, d_adds, ob, hipMemcpyDeviceToHost));
   return 0;
-}
+} HEP_CATCH_INT
 
 // ---- training side ----
 int hep_anchor_targets_device(const float* anchors, int num_anchors, const double* gt_boxes, const int32_t* gt_labels,
                               const float* gt_transform, const float* gt_coords, const int32_t* num_gt, const int32_t* image_hw,
                               int batch, int kmax, int num_classes, int num_transform, double negative_overlap, double positive_overlap,
-                              float* labels, float* regression, float* transformation, float* coords, void* stream) {
+                              float* labels, float* regression, float* transformation, float* coords, void* stream) try {
   if (!anchors || !gt_boxes || !gt_labels || !gt_transform || !num_gt || !image_hw || !labels || !regression || !transformation)
     return fail(HEP_ERR_INVALID, "bad argument");
   if (num_anchors < 1 || batch < 1 || num_classes < 1 || num_transform < 0) return fail(HEP_ERR_INVALID, "bad size");
@@ -597,12 +626,12 @@ int hep_anchor_targets_device(const float* anchors, int num_anchors, const doubl
   launch_anchor_targets(a, (hipStream_t)stream);
   HIPRET(hipGetLastError());
   return 0;
-}
+} HEP_CATCH_INT
 
 int hep_losses_device(const float* gt_classification, const float* classification, const float* gt_regression, const float* regression,
                       const float* gt_transformation, const float* transformation, const float* gt_hand, const float* hand,
                       const float* model_points, int batch, int num_anchors, int num_classes, int num_rotation, int num_hand,
-                      int num_model_classes, int num_points, float* per_image, float* losses, void* stream) {
+                      int num_model_classes, int num_points, float* per_image, float* losses, void* stream) try {
   if (!gt_classification || !classification || !gt_regression || !regression || !gt_transformation || !transformation || !model_points ||
       !per_image || !losses) return fail(HEP_ERR_INVALID, "bad argument");
   if ((gt_hand == nullptr) != (hand == nullptr)) return fail(HEP_ERR_INVALID, "gt_hand and hand go together");
@@ -614,18 +643,18 @@ int hep_losses_device(const float* gt_classification, const float* classificatio
   launch_losses(a, (hipStream_t)stream);
   HIPRET(hipGetLastError());
   return 0;
-}
+} HEP_CATCH_INT
 
 // ---- introspection ----
-int hep_debug_tensor_count(const hep_handle* h) { return h ? (int)h->s.tensors.size() : 0; }
-int hep_debug_tensor_info(const hep_handle* h, int i, const char** name, int64_t dims[4]) {
+int hep_debug_tensor_count(const hep_handle* h) try { return h ? (int)h->s.tensors.size() : 0; } HEP_CATCH_INT
+int hep_debug_tensor_info(const hep_handle* h, int i, const char** name, int64_t dims[4]) try {
   if (!h || i < 0 || i >= (int)h->s.tensors.size()) return fail(HEP_ERR_INVALID, "bad tensor index");
   const TensorDesc& t = h->s.tensors[i];
   if (name) *name = t.name.c_str();
   if (dims) { dims[0] = h->s.max_batch; dims[1] = t.H; dims[2] = t.W; dims[3] = t.C; }
   return 0;
-}
-int hep_debug_tensor(hep_handle* h, const char* name, int batch, float* out, size_t capacity) {
+} HEP_CATCH_INT
+int hep_debug_tensor(hep_handle* h, const char* name, int batch, float* out, size_t capacity) try {
   if (!h || !name || !out) return fail(HEP_ERR_INVALID, "bad argument");
   Session& s = h->s;
   auto it = s.tensor_by_name.find(name);
@@ -649,10 +678,10 @@ int hep_debug_tensor(hep_handle* h, const char* name, int batch, float* out, siz
     }
   }
   return 0;
-}
+} HEP_CATCH_INT
 
-int hep_kernel_count(const hep_handle* h, int) { return h ? (int)h->s.ops.size() : 0; }
-int hep_kernel_info(const hep_handle* h, int batch, int i, const char** name, double* bytes, double* flops) {
+int hep_kernel_count(const hep_handle* h, int) try { return h ? (int)h->s.ops.size() : 0; } HEP_CATCH_INT
+int hep_kernel_info(const hep_handle* h, int batch, int i, const char** name, double* bytes, double* flops) try {
   if (!h || i < 0 || i >= (int)h->s.ops.size()) return fail(HEP_ERR_INVALID, "bad kernel index");
   const Op& o = h->s.ops[i];
   if (name) *name = o.name.c_str();
@@ -660,25 +689,25 @@ int hep_kernel_info(const hep_handle* h, int batch, int i, const char** name, do
   if (bytes) *bytes = o.act_bytes_per_image * per_launch + o.weight_bytes;
   if (flops) *flops = o.flops_per_image * per_launch;
   return 0;
-}
+} HEP_CATCH_INT
 
-int hep_fp8_scale(const hep_handle* h, int i, float* a_scale) {
+int hep_fp8_scale(const hep_handle* h, int i, float* a_scale) try {
   if (!h || !a_scale || i < 0 || i >= (int)h->s.ops.size()) return fail(HEP_ERR_INVALID, "bad kernel index");
   const Op& o = h->s.ops[i];
   *a_scale = (o.kind == OP_PW && o.pw.fp8) ? o.pw.a_scale : ((o.kind == OP_MBF && o.mbf.fp8) ? o.mbf.a_scale : 0.f);
   return 0;
-}
+} HEP_CATCH_INT
 
-int hep_calibrate_fp8(hep_handle* h, const float* frames_nchw_device, int batch) {
+int hep_calibrate_fp8(hep_handle* h, const float* frames_nchw_device, int batch) try {
   if (!h || !frames_nchw_device || batch < 1) return fail(HEP_ERR_INVALID, "bad argument");
   Session& s = h->s;
   if (s.dtype != HEP_FP8) return fail(HEP_ERR_UNSUPPORTED, "hep_calibrate_fp8 needs an HEP_FP8 session");
   std::lock_guard<std::mutex> lk(s.mu);
   HIPRET(hipDeviceSynchronize());
   return calibrate_fp8(s, frames_nchw_device, batch);
-}
+} HEP_CATCH_INT
 
-int hep_kernel_symbol(const hep_handle* h, int i, const char** symbol) {
+int hep_kernel_symbol(const hep_handle* h, int i, const char** symbol) try {
   if (!h || !symbol || i < 0 || i >= (int)h->s.ops.size()) return fail(HEP_ERR_INVALID, "bad kernel index");
   static thread_local std::string buf;
   const Op& o = h->s.ops[i];
@@ -709,7 +738,7 @@ int hep_kernel_symbol(const hep_handle* h, int i, const char** symbol) {
   }
   buf = tmp; *symbol = buf.c_str();
   return 0;
-}
+} HEP_CATCH_INT
 
 namespace {
 struct EventSet {     // events and streams of the profilers, released on every return path
@@ -720,7 +749,7 @@ struct EventSet {     // events and streams of the profilers, released on every 
 };
 }  // namespace
 
-int hep_profile(hep_handle* h, int batch, int iters, float* total_ms_per_iter, float* per_kernel_ms) {
+int hep_profile(hep_handle* h, int batch, int iters, float* total_ms_per_iter, float* per_kernel_ms) try {
   if (!h || iters < 1) return fail(HEP_ERR_INVALID, "bad argument");
   Session& s = h->s;
   if (batch < 1 || batch > s.max_batch) return fail(HEP_ERR_UNSUPPORTED, "batch outside 1..max_batch");
@@ -761,9 +790,9 @@ int hep_profile(hep_handle* h, int batch, int iters, float* total_ms_per_iter, f
     for (size_t k = 0; k < n; k++) per_kernel_ms[k] = (float)(acc[k] / iters);
   }
   return 0;
-}
+} HEP_CATCH_INT
 
-int hep_profile_concurrent(hep_handle* h, int batch, int iters, int nstreams, float* per_kernel_ms) {
+int hep_profile_concurrent(hep_handle* h, int batch, int iters, int nstreams, float* per_kernel_ms) try {
   if (!h || iters < 1 || nstreams < 1 || nstreams > 16 || !per_kernel_ms) return fail(HEP_ERR_INVALID, "bad argument");
   Session& s = h->s;
   if (batch < 1 || batch > s.max_batch) return fail(HEP_ERR_UNSUPPORTED, "batch outside 1..max_batch");
@@ -791,6 +820,6 @@ int hep_profile_concurrent(hep_handle* h, int batch, int iters, int nstreams, fl
     }
   }
   return 0;
-}
+} HEP_CATCH_INT
 
 }  // extern "C"

@@ -71,6 +71,7 @@ struct Session {
   // device memory
   unsigned char* d_weights = nullptr; size_t weights_bytes = 0;
   uint8_t* d_pre[2] = {nullptr, nullptr}; size_t pre_bytes[2] = {0, 0};   // hep_preprocess_i420_device: cropped BGR frames, resized frames
+  hipEvent_t pre_event = nullptr; bool pre_pending = false;              // recorded behind the last launch that used d_pre: the next call's stream waits for it
   unsigned char* d_arena = nullptr; size_t arena_bytes = 0;
   float* d_out[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // regression, classification, rotation, translation_raw, hand
   float* d_in = nullptr;            // staging for host-buffer runs

@@ -141,6 +141,41 @@ def gather_detections(det: Dict[str, torch.Tensor], global_batch: int, dst: int 
     return {k: torch.cat(v, 0) for k, v in bufs.items()}
 
 
+def describe(local_rank: int) -> str:
+    """One line per rank for the job log, printed BEFORE the first collective: rank / world, backend, RCCL (nccl) version as
+    torch reports it and the device this rank drives - the first thing to read when an N-GPU run misbehaves."""
+    rank, world = (dist.get_rank(), dist.get_world_size()) if (dist.is_available() and dist.is_initialized()) else (0, 1)
+    be = dist.get_backend() if world > 1 else "none"
+    ver = "n/a"
+    try:
+        if torch.cuda.is_available():
+            ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception as e:       # (a build without nccl bindings: report, never fail the job over a log line)
+        ver = f"unavailable ({type(e).__name__})"
+    name = torch.cuda.get_device_properties(local_rank).name if torch.cuda.is_available() else "cpu"
+    return f"rank {rank}/{world}: backend {be}, nccl/RCCL {ver}, device cuda:{local_rank} = {name}, HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '(unset)')}"
+
+
+def warm_up_p2p(device: torch.device, root: int = 0) -> None:
+    """One tiny message root -> peer and peer -> root for every peer, then a barrier.  RCCL creates its point-to-point
+    communicators (and maps the peer's memory over xGMI) lazily on the first send / receive between two ranks; without this
+    that set-up would sit inside the first timed steps of the scatter / gather loop."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    rank, world = dist.get_rank(), dist.get_world_size()
+    peers = [r for r in range(world) if r != root] if rank == root else [root]
+    out = [torch.full((16,), float(rank), dtype=torch.float32, device=device) for _ in peers]
+    inp = [torch.empty((16,), dtype=torch.float32, device=device) for _ in peers]
+    ops = []
+    for p, o, i in zip(peers, out, inp):
+        ops.append(dist.P2POp(dist.isend, _wire(o), p))
+        w = _wire(i)
+        ops.append(dist.P2POp(dist.irecv, w, p))
+    for q in dist.batch_isend_irecv(ops):
+        q.wait()
+    dist.barrier()
+
+
 def max_over_ranks(seconds: float, device: torch.device) -> float:
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return seconds

@@ -406,9 +406,32 @@ class TrainModelWithLoss(nn.Module):
                                    int(max_detections), s.handle)
         return dict(zip(_FILTER_KEYS, out))
 
-    def forward(self, imgs, camera_params, is_losses=False, params=None, **kwargs):
+    @torch.no_grad()
+    def validation_losses(self, imgs, camera_params, model_3d_points, classification_gt, regression_gt, transformation_gt, coords_3d_gt=None,
+                          num_rotation_parameters: int = 3):
+        """The ``is_losses=True`` branch of the reference wrapper (train.py:42-70) as FORWARD VALUES: HIP forward -> translation
+        decode (``format_translation``) -> ``batch_iterate`` on the device (hep_losses_device) -> the reference's loss weights
+        (rotation x 100, translation x 0.1) and their sum.  Six 0-dim float32 tensors on the device, in the reference's order
+        [classification, regression, rotation, translation, hands, total].  No autograd graph: this is what a validation pass
+        logs; optimising through the HIP forward is out of scope (the model refuses ``train()`` mode)."""
+        from . import training
+        _, regression, classification, rotation, translation_raw, hand = self.model(imgs)
+        s = self.model.session(int(imgs.shape[-1]), int(imgs.shape[0]), imgs.device)
+        _boxes, translation = torch.ops.hep.decode(regression, translation_raw, camera_params.to(imgs.device, torch.float32), s.handle)
+        f = lambda t: None if t is None else torch.as_tensor(t).to(imgs.device, torch.float32)
+        out, _per = training.losses(f(classification_gt), classification, f(regression_gt), regression, f(transformation_gt),
+                                    torch.cat((rotation, translation), dim=2), f(coords_3d_gt), hand if coords_3d_gt is not None else None,
+                                    model_3d_points, num_rotation_parameters)
+        cls_l, reg_l, rot_l, tr_l, hand_l = out[0] * 1.0, out[1] * 1.0, out[2] * 100, out[3] * 0.1, out[4] * 1.0      # train.py:61-65
+        return [cls_l, reg_l, rot_l, tr_l, hand_l, cls_l + reg_l + rot_l + tr_l + hand_l]
+
+    def forward(self, imgs, camera_params, is_losses=False, model_3d_points=None, classification_gt=None, regression_gt=None,
+                transformation_gt=None, coords_3d_gt=None, params=None, **kwargs):
         if is_losses:
-            raise NotImplementedError("loss computation (train.py:42-70) is training-side and out of scope for the MI355X inference path")
+            if model_3d_points is None or classification_gt is None or regression_gt is None or transformation_gt is None:
+                raise ValueError("is_losses=True needs model_3d_points, classification_gt, regression_gt and transformation_gt (train.py:189-197)")
+            return self.validation_losses(imgs, camera_params, model_3d_points, classification_gt, regression_gt, transformation_gt, coords_3d_gt,
+                                          int((params or {}).get("num_rotation_parameters", 3)))
         d = self.detect(imgs, camera_params)
         last = imgs.shape[0] - 1
         return [d[k][last].cpu() for k in ("boxes", "scores", "labels", "rotation", "translation", "hand")]

@@ -28,7 +28,7 @@
  *                                 metric arithmetic of evaluate.py's loop, eval/common.py:866-1121)
  *
  * Conventions: plain pointers and sizes only; every function returns 0 on success or a
- * negative hep_status, never throws and never aborts; hep_last_error() gives a thread-local
+ * negative hep_status, never throws (every entry point catches what its C++ body could raise -> HEP_ERR_INTERNAL) and never aborts; hep_last_error() gives a thread-local
  * message.  A handle serialises its own calls with an internal mutex (the C# frame callback
  * re-enters Run from WebRTC worker threads, Program.cs:128); several handles may coexist.
  * There is NO CPU fallback: without a usable gfx950 device hep_create fails.
@@ -52,7 +52,8 @@ typedef enum hep_status {
   HEP_ERR_INVALID = -1,      /* bad argument                                  */
   HEP_ERR_PACK = -2,         /* weight pack missing / malformed / wrong shape  */
   HEP_ERR_DEVICE = -3,       /* HIP error or no gfx950 device                  */
-  HEP_ERR_UNSUPPORTED = -4   /* phi / size / batch outside the built range     */
+  HEP_ERR_UNSUPPORTED = -4,  /* phi / size / batch outside the built range     */
+  HEP_ERR_INTERNAL = -5      /* a C++ exception (out of host memory, ...) was caught at the ABI: nothing ever propagates into the caller */
 } hep_status;
 
 typedef enum hep_dtype {
@@ -226,7 +227,7 @@ int hep_fp8_scale(const hep_handle* h, int i, float* a_scale);
  * frames of pseudo-normal noise with 2x headroom; the e4m3 conversion SATURATES silently at +-448 * scale.  Real frames
  * (normalised to about [-2.1, 2.6], structured, zero-padded) through trained weights can exceed that range in the deeper
  * layers: recalibrate on representative frames before serving.  frames: contiguous fp32 [batch,3,S,S] on the session's
- * device (at most the session's max_batch frames are used).  Not to be called while a run is in flight on this handle.
+ * device (the first min(batch, frames per lane) frames are used: all of max_batch with the default single lane, max_batch / HEP_LANES otherwise).  Not to be called while a run is in flight on this handle.
  * Replaces the fixed scales of ONNXRuntime's static quantisation tables, which the reference does not use (fp32 ORT). */
 int hep_calibrate_fp8(hep_handle* h, const float* frames_nchw_device, int batch);
 /* Device function (as rocprofv3 --kernel-trace names it, e.g. "sep_kernel<true>") behind launch i. */

@@ -10,7 +10,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from hmd_ego_pose_amd.dist import broadcast_state_dict, gather_detections, max_over_ranks, scatter_frames, shard_range
+from hmd_ego_pose_amd.dist import broadcast_state_dict, describe, gather_detections, max_over_ranks, scatter_frames, shard_range, warm_up_p2p
 
 
 def test_shard_range_covers_batch_contiguously():
@@ -35,6 +35,10 @@ def _worker(rank, world, port, q, G=5):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cpu")
     try:
+        # the per-rank job-log line and the point-to-point warm-up bench.py issues before its timed serving loop
+        line = describe(0)
+        assert f"rank {rank}/{world}" in line and "backend gloo" in line
+        warm_up_p2p(dev)
         # weights: rank 0's values must arrive everywhere
         state = {"a.weight": torch.full((3, 4), float(rank + 1)), "b.num_batches_tracked": torch.tensor(rank), "c.bias": torch.arange(5.) * (rank + 1)}
         out = broadcast_state_dict(state, dev)
@@ -100,8 +104,12 @@ def test_bench_refuses_more_gpus_than_visible_before_touching_one():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "64", "--steps", "1", "--warmup", "0"], env=env,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "GPU(s) visible" in r.stderr, (r.returncode, r.stderr[-400:])
-    # under a torchrun-style environment a rank whose local rank has no device exits before the rendezvous
-    env2 = dict(env, WORLD_SIZE="2", RANK="1", LOCAL_RANK="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env2,
+    # under a torchrun-style environment a rank whose local rank has no device exits before the rendezvous (the local rank is
+    # the first one BEYOND the devices this host has - on a multi-GPU box LOCAL_RANK=1 owns a device and would wait in the
+    # rendezvous for its peers)
+    import torch
+    nd = torch.cuda.device_count()
+    env2 = dict(env, WORLD_SIZE=str(nd + 1), RANK=str(nd), LOCAL_RANK=str(nd), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(nd + 1), "--steps", "1", "--warmup", "0"], env=env2,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "GPU(s) visible" in (r.stderr + r.stdout), (r.returncode, r.stderr[-400:])

@@ -97,3 +97,29 @@ def test_webrtc_frame_path_against_oracle(env, size):
     rc = _capi.lib().hep_preprocess_i420_device(s.handle, got.data_ptr(), 1, 481, 640, 256, 512, got.data_ptr(), None)
     assert rc == -1 and b"even" in _capi.lib().hep_last_error()
     s.close()
+
+
+def test_webrtc_frame_path_from_several_streams_on_one_handle(env):
+    """The frame path's two scratch frames belong to the handle and are used asynchronously on the CALLER's stream: calls from
+    different streams (an in-flight pool) are ordered by an event recorded behind each call, so a later call never overwrites
+    scratch an earlier call's kernels still read.  Eight different frame sets go through one handle on four streams back to
+    back with no host synchronisation in between; every result must equal the oracle's."""
+    Session, sd_of, D = env
+    size, (h, w, crop, rs) = 256, (720, 1280, 256, 512)
+    s = Session(sd_of(0, 0), 0, size, 3, "fp32")
+    rng = np.random.Generator(np.random.PCG64(5))
+    bufs = [rng.integers(0, 256, (3, h * w * 3 // 2), dtype=np.uint8) for _ in range(8)]
+    dev = [torch.from_numpy(b).cuda() for b in bufs]
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    torch.cuda.synchronize()
+    outs = []
+    for rep in range(3):                                  # the first round also grows the scratch buffers
+        outs = []
+        for i, x in enumerate(dev):
+            with torch.cuda.stream(streams[i % 4]):
+                outs.append(s.preprocess_i420(x, h, w, crop, rs))
+    torch.cuda.synchronize()
+    for i, (b, got) in enumerate(zip(bufs, outs)):
+        want = np.stack([D.webrtc_frame_preprocess(f, h, w, size, crop, rs)[0] for f in b])
+        assert np.array_equal(got.permute(0, 2, 3, 1).cpu().numpy(), want), i
+    s.close()

@@ -154,6 +154,37 @@ def test_corrupt_pack_is_refused_without_reading_out_of_bounds():
         assert rc == -2 and b"weight pack" in l.hep_last_error(), (dims, off, nb, rc, l.hep_last_error())
 
 
+def test_no_cpp_exception_crosses_the_c_abi():
+    """include/hep.h: "never throws".  Every extern "C" entry point is a function-try-block (csrc/hep_api.cpp): a std::bad_alloc /
+    length_error raised while a hostile pack is copied, or anything else a C++ body could throw, comes back as HEP_ERR_INTERNAL
+    with a message instead of unwinding into a ctypes / P/Invoke caller (which terminates the process).  Truncated tables and
+    oversized headers are plain HEP_ERR_PACK."""
+    import struct
+    l = _capi.lib()
+    h = ctypes.c_void_p()
+    good = pack_bytes(seeded_state_dict(0, 0))
+    # (1) a size far beyond what the host can allocate: the parser's copy of the pack throws before a byte is read
+    buf = ctypes.create_string_buffer(bytes(good[:4096]), 4096)
+    for huge in (1 << 62, (1 << 63) + 5):
+        rc = l.hep_create_from_memory(buf, huge, 0, 256, 1, _capi.HEP_F32, 0, 0, ctypes.byref(h))
+        assert rc == -5 and not h.value, (huge, rc, l.hep_last_error())
+        assert b"memory" in l.hep_last_error() or b"internal error" in l.hep_last_error()
+    # (2) truncated packs: every prefix that cuts the table or the data
+    for cut in (12, 13, 20, 100, len(good) // 2, len(good) - 100):
+        rc = l.hep_create_from_memory(good[:cut], cut, 0, 256, 1, _capi.HEP_F32, 0, 0, ctypes.byref(h))
+        assert rc == -2 and b"weight pack" in l.hep_last_error(), (cut, rc, l.hep_last_error())
+    # (3) oversized headers: a tensor count, a name length and a rank no file of this size can hold
+    hdr = lambda count: b"HEPW" + struct.pack("<II", 1, count)
+    for blob in (hdr(0xFFFFFFFF) + bytes(64),
+                 hdr(1) + struct.pack("<H", 0xFFFF) + b"t" * 32,
+                 hdr(1) + struct.pack("<H", 1) + b"t" + bytes([200]) + bytes(64),
+                 hdr(3) + struct.pack("<H", 1) + b"t" + bytes([1]) + struct.pack("<I", 2) + struct.pack("<QQ", 64, 8) + bytes(64)):
+        rc = l.hep_create_from_memory(blob, len(blob), 0, 256, 1, _capi.HEP_F32, 0, 0, ctypes.byref(h))
+        assert rc == -2 and b"weight pack" in l.hep_last_error() and not h.value, (blob[:24], rc, l.hep_last_error())
+    # the library still works afterwards
+    assert l.hep_abi_version() == 1 and l.hep_anchors(256, None, None) == 12276
+
+
 def test_evaluator_host_logic(tmp_path):
     """hmd_ego_pose_amd.evaluate without a GPU: the Linemod-folder reader (binary and ASCII PLY, yml, split file, mask
     boxes), Rodrigues both ways against scipy, IoU with the +1 convention, AP, and the post-filter (a15) against the
