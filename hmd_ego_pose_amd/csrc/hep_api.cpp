@@ -724,7 +724,9 @@ int hep_kernel_symbol(const hep_handle* h, int i, const char** symbol) try {
     case OP_PWG: snprintf(tmp, sizeof tmp, "pw_group_kernel<%s>", t); break;
     case OP_CHAIN: snprintf(tmp, sizeof tmp, "chain_kernel<%s, %s>", o.chain.bf16 ? "true" : "false", o.chain.stream_w ? "true" : "false"); break;
     case OP_SE: snprintf(tmp, sizeof tmp, "se_finish_kernel<%s>", t); break;
-    case OP_MBF: snprintf(tmp, sizeof tmp, "mbf_kernel<%s, %d, %d, %d>", t, o.mbf.k, o.mbf.s, o.mbf.ts); break;
+    case OP_MBF: if (o.mbf.has_expand && o.mbf.npass > 1) snprintf(tmp, sizeof tmp, "mbf_kernel<%s, %d, %d, %d, false, %d>", t, o.mbf.k, o.mbf.s, o.mbf.ts, o.mbf.mp_resident ? 2 : 1);      // (multi-pass expand)
+                 else snprintf(tmp, sizeof tmp, "mbf_kernel<%s, %d, %d, %d>", t, o.mbf.k, o.mbf.s, o.mbf.ts);
+                 break;
     case OP_SBF: snprintf(tmp, sizeof tmp, "sbf_kernel<%s>", t); break;
     case OP_XBF: { const int sp = xbf_specialised(o.xbf);
                    snprintf(tmp, sizeof tmp, "xbf_kernel<%s, %d, %d, %d, %d, %d, %d, %d>", t, o.xbf.k, o.xbf.s, o.xbf.toh, o.xbf.tow, o.xbf.NT1, sp ? o.xbf.K1 : 0, sp ? o.xbf.NT2 : 0); break; }

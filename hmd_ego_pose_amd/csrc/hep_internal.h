@@ -100,6 +100,9 @@ struct MbfArgs {
   int B, H, W, Cin, Cexp, Ho, Wo, k, s, pad_t, pad_l, has_expand, bf16;
   int CC;              // expanded channels per workgroup (8 * power of two)
   int ts;              // output tile side: 8, or 16 (stride-1 layers on maps >= 16x16; k_mbf.hip)
+  int npass, kp;       // multi-pass expand: K input channels in npass slices of kp (npass <= 1: one pass, the whole K staged at once)
+  int mp_resident;     // multi-pass: the whole tile is requested at kernel start and held in registers (else slice by slice)
+  uint32_t vk_rcp, kpv_rcp;                     // filled by launch_mbf: rcp_u32 of K / 8 and kp / 8
   size_t off_e, off_we, off_w, lds_bytes;
   int fp8; const float* we_scale; float a_scale;   // fp8 sessions: e4m3 expand weights (rows padded to 16 bytes), per-channel / per-tensor scales
   int trace;           // profiling builds (-DHEP_MBF_TRACE): this launch writes its phase time stamps
@@ -266,7 +269,9 @@ void launch_pwg(const PwgArgs&, hipStream_t);
 void launch_dw(const DwArgs&, hipStream_t);
 void launch_pool(const PoolArgs&, hipStream_t);
 void launch_mbf(const MbfArgs&, hipStream_t);
-size_t mbf_lds_layout(int Cin, int CC, int k, int s, int bf16, int has_expand, int max_inside, int ts, MbfArgs* a);
+size_t mbf_lds_layout(int Cin, int CC, int k, int s, int bf16, int has_expand, int max_inside, int ts, MbfArgs* a, int kp = 0);
+int mbf_mp_fits(int CC, int kp, int bf16, int max_inside, int ts);     // the multi-pass plan fits the kernel's compile-time budgets
+int mbf_mp_resident(int Cin, int CC, int max_inside, int ts);          // ... with the whole tile held in registers
 int mbf_max_inside(int H, int W, int k, int s, int pad_t, int pad_l, int ts);
 int mbf_prepare(void);
 void launch_sep(const SepArgs&, hipStream_t);

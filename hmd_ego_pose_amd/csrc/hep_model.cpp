@@ -526,7 +526,7 @@ struct Planner {
         mbf_lds_layout(b.cin, 32, b.k, b.stride, s->dtype, b.expand, max_in, ts, nullptr) > 159 * 1024) {
       ts = 8; max_in = mbf_max_inside(Hin, Win, b.k, b.stride, pt, pl, ts);
     }
-    int CC = 0;
+    int CC = 0, npass = 1, kp = 0;
     // Measured on MI355X at bs16 (profiles/README.md): the fused kernel beats expand+depthwise on input
     // maps up to 32x32 (it expands only the tile pixels inside the image, so on the 8x8 maps the halo costs
     // nothing) and loses on the big early maps (bandwidth-bound, the two-kernel path already streams well;
@@ -537,6 +537,43 @@ struct Planner {
     if (want && !(mode && !strcmp(mode, "none")))
       for (int cand : {64, 32, 16})
         if (mbf_lds_layout(b.cin, std::min(cand, b.expand ? cand : b.cexp), b.k, b.stride, s->dtype, b.expand, max_in, ts, nullptr) <= 159 * 1024) { CC = cand; break; }
+    // fp32 sessions (HEP_MBF_MP=0 disables, =1 also for bf16): the tile / channel chunk / K-slice plan with the fewest ROUNDS of
+    // workgroups.  With the whole K staged at once an fp32 front needs twice the LDS of the bf16 one: the 16x16 tile of blocks 9,
+    // 10 fell back to 8x8 (704 workgroups on 256 CUs: three rounds, 37 us against 17 us in bf16), the 8x8 maps kept one workgroup
+    // of 146 KB per CU where 288 want to be resident (two rounds).  The multi-pass expand (k_mbf.hip, MP) stages K in slices and
+    // gives fp32 the workgroup counts of the bf16 plan.
+    {
+      const char* e = getenv("HEP_MBF_MP");
+      const bool force = e && !strcmp(e, "force");                  // parity runs: the multi-pass form wherever it exists, whatever the rounds
+      const bool mp_on = e ? (force || (atoi(e) != 0 && (s->dtype == 0 || atoi(e) == 1))) : s->dtype == 0;
+      if (CC && b.expand && mp_on && s->dtype != 2) {
+        struct Cand { int ts, CC, npass, kp; long rounds; size_t lds; };
+        const int kstep = s->dtype ? 32 : 16, ksteps = (b.cin + kstep - 1) / kstep;
+        auto rounds_of = [&](int ts_, int cc_, size_t lds) {
+          const long tiles = (long)((Ho + ts_ - 1) / ts_) * ((Wo + ts_ - 1) / ts_), wgs = tiles * ((b.cexp + cc_ - 1) / cc_) * s->lane_batch;
+          const long per_cu = std::max<long>(1, std::min<long>((long)(160 * 1024 / lds), ts_ == 16 ? 2 : 4));
+          return (wgs + 256 * per_cu - 1) / (256 * per_cu);
+        };
+        Cand best{ts, CC, 1, 0, rounds_of(ts, CC, mbf_lds_layout(b.cin, CC, b.k, b.stride, s->dtype, 1, max_in, ts, nullptr)), 0};
+        const bool ts16_ok = b.stride == 1 && Ho >= 16 && Ho <= ts16_maxh && !(getenv("HEP_MBF_TS") && atoi(getenv("HEP_MBF_TS")) == 8);
+        for (int ts_ : {16, 8}) {
+          if (ts_ == 16 && !ts16_ok) continue;
+          const int mi = mbf_max_inside(Hin, Win, b.k, b.stride, pt, pl, ts_);
+          for (int cc_ : {64, 32})
+            for (int kpp = 3; kpp >= 1; kpp--) {              // k-steps per pass
+              const int kp_ = kpp * kstep, np_ = (b.cin + kp_ - 1) / kp_;
+              if (np_ < 2 || kpp > ksteps || !mbf_mp_fits(cc_, kp_, s->dtype, mi, ts_)) continue;
+              const size_t lds = mbf_lds_layout(b.cin, cc_, b.k, b.stride, s->dtype, 1, mi, ts_, nullptr, kp_);
+              if (lds > 159 * 1024) continue;
+              const Cand c{ts_, cc_, np_, kp_, rounds_of(ts_, cc_, lds), lds};
+              // fewer rounds first; then fewer passes (two barriers each); then the wider chunk
+              if (c.rounds < best.rounds || (force && best.npass == 1) ||
+                  (c.rounds == best.rounds && best.npass > 1 && (c.npass < best.npass || (c.npass == best.npass && c.CC > best.CC)))) best = c;
+            }
+        }
+        if (best.npass > 1) { ts = best.ts; CC = best.CC; npass = best.npass; kp = best.kp; max_in = mbf_max_inside(Hin, Win, b.k, b.stride, pt, pl, ts); }
+      }
+    }
     // squeeze-excite weights: reduce FC [sq][Cexp] (fp32) for the front kernel; bias, expand FC [Cexp][sqp] (session
     // dtype, rows padded with zeros) and its bias for the project GEMM's prologue
     const PackTensor *wr = get(p + "._se_reduce.conv.weight", {b.se, b.cexp, 1, 1}), *br = get(p + "._se_reduce.conv.bias", {b.se}),
@@ -575,7 +612,12 @@ struct Planner {
       MbfArgs& m = o.mbf; memset(&m, 0, sizeof m);
       m.H = Hin; m.W = Win; m.Cin = b.cin; m.Cexp = b.cexp; m.Ho = Ho; m.Wo = Wo; m.k = b.k; m.s = b.stride;
       m.pad_t = pt; m.pad_l = pl; m.has_expand = b.expand; m.bf16 = s->dtype; m.CC = CC; m.sq = b.se; m.sqp = sqp; m.ts = ts;
-      mbf_lds_layout(b.cin, CC, b.k, b.stride, s->dtype, b.expand, max_in, ts, &m);
+      m.npass = npass; m.kp = kp;
+      // (the register-resident form - the whole tile requested at kernel start, parked slice by slice - measured SLOWER than fetching
+      //  slice by slice: 8x8 maps 24.1 us against 22.4 us per launch, blocks 9 / 10 31.4 against 29.6: a pass is not bound by its
+      //  memory round trip but by its three phase changes, ~1 us per pass whatever feeds it; HEP_MBF_MP_RES=1 selects it)
+      m.mp_resident = npass > 1 && mbf_mp_resident(b.cin, CC, max_in, ts) && getenv("HEP_MBF_MP_RES") && atoi(getenv("HEP_MBF_MP_RES")) != 0;
+      mbf_lds_layout(b.cin, CC, b.k, b.stride, s->dtype, b.expand, max_in, ts, &m, kp);
       wref(op, F_MBF_WR, wr_off);
       if (b.expand) {
         const PackTensor* w = get(p + "._expand_conv.conv.weight", {b.cexp, b.cin, 1, 1});

@@ -54,7 +54,16 @@ __device__ unsigned long long* g_mbf_trace = nullptr;
 
 // F8: e4m3 operands in the expand MFMA (fp8 sessions).  A template parameter: as a run-time flag both operand paths sat in
 // the expand loop of every bf16 session and kept it from unrolling (340 instructions per 32-pixel x 16-channel item).
-template <bool BF16, int KS, int S, int TS, bool F8>
+// MP: the expand conv runs in several passes over slices of its K input channels (a.kp channels per pass): per pass the slice of
+// the input tile and of the weight chunk is staged in LDS and every wave adds its products to accumulators that stay in
+// registers.  fp32 sessions: a whole-K input tile next to the expanded tile does not fit LDS for the 16x16 tile (blocks 9, 10
+// fell back to 8x8 tiles = 704 workgroups = three rounds) or leaves one workgroup per CU where 288 want to be resident (the 8x8
+// maps: two rounds).  With K in slices the fp32 fronts get the workgroup counts of the bf16 plan.
+// MP = 1: the slices are fetched pass by pass (the next one under the running pass's MFMAs: a pass is then about one memory round
+// trip, ~2 us); MP = 2: the WHOLE input tile and weight chunk are requested at kernel start into registers (up to six 8-channel
+// vectors per lane: one round trip for the launch, as in the single-pass form) and only parked slice by slice - chosen whenever
+// the vectors fit (mbf_mp_fits).
+template <bool BF16, int KS, int S, int TS, bool F8, int MP>
 __global__ __launch_bounds__(TS == 16 ? 1024 : 512) void mbf_kernel(MbfArgs a) {
   constexpr int MBF_THREADS = TS == 16 ? 1024 : 512, MBF_WAVES = MBF_THREADS / 64;
   typedef Vec8<BF16> V;
@@ -87,7 +96,7 @@ __global__ __launch_bounds__(TS == 16 ? 1024 : 512) void mbf_kernel(MbfArgs a) {
   const int c0 = chunk * a.CC;                                     // first expanded channel of this block
   const int cc = min(a.CC, a.Cexp - c0);                           // channels of this block (multiple of 8)
   const int K = a.Cin;
-  const int KP = K + PAD, EP = a.CC + PAD;                         // LDS row pitches (elements)
+  const int KP = (MP ? a.kp : K) + PAD, EP = a.CC + PAD;           // LDS row pitches (elements)
   T* a_s = reinterpret_cast<T*>(smem);                             // [PIN][KP]   input tile
   T* e_s = reinterpret_cast<T*>(smem + a.off_e);                   // [PIN][EP]   expanded (activated) tile
   T* w_s = reinterpret_cast<T*>(smem + a.off_we);                  // [CC][KP]    expand-weight chunk
@@ -146,7 +155,154 @@ __global__ __launch_bounds__(TS == 16 ? 1024 : 512) void mbf_kernel(MbfArgs a) {
     // thread -> (row, vector): vectors rounded up to a power of two so the split is a shift and a mask
     const int vsh = vecs <= 1 ? 0 : 32 - __builtin_clz(vecs - 1);
     const int v = threadIdx.x & ((1 << vsh) - 1), row0 = threadIdx.x >> vsh, rstride = MBF_THREADS >> vsh;
-    if (a.has_expand) {
+    if constexpr (MP != 0) {
+      // ---- multi-pass expand (see the template comment): pass p = input channels [p * kp, (p + 1) * kp) ----
+      const int Kp = a.kp, npass = a.npass, n_wrows = ntiles * 16;
+      const int pvecs = Kp >> 3;                                     // 8-channel vectors per row and pass
+      const int pvsh = pvecs <= 1 ? 0 : 32 - __builtin_clz(pvecs - 1);
+      const int pv = threadIdx.x & ((1 << pvsh) - 1), prow0 = threadIdx.x >> pvsh, prs = MBF_THREADS >> pvsh;
+      constexpr int NIW = TS == 16 ? 1 : 2, NIP = TS == 16 ? 2 : 3;   // row batches per lane and pass (host-checked: mbf_mp_fits)
+      const unsigned char* w_b = reinterpret_cast<const unsigned char*>(a.we) + (int64_t)c0 * K * (int)sizeof(T);
+      const int pix0 = (iy0 + r0) * a.W + ix0 + q0;
+      constexpr bool RES = MP == 2;
+      // RES: item i = tid + j * threads of the (weight rows + inside pixels) x (K / 8 vectors) grid; everything in flight at once
+      constexpr int NJ = RES ? 6 : 1;
+      raw_t rq0[NJ], rq1[NJ]; int qdst[NJ], qsl[NJ];                   // vectors, LDS element offset (>= 0: in a_s, < 0: -(1 + offset) in w_s), slice
+      if constexpr (RES) {
+        const int vk_ = K >> 3;
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+          const int i = threadIdx.x + j * MBF_THREADS, row = udiv_rcp(i, a.vk_rcp), vec = i - row * vk_;
+          const bool ok = row < n_wrows + n_in, is_w = row < n_wrows;
+          const int m = min(max(row - n_wrows, 0), n_in - 1), ri = row_of(m);
+          const uint32_t off_w = (uint32_t)(min(row, n_wrows - 1) * K + vec * 8) * (uint32_t)sizeof(T);
+          const uint32_t off_p = (uint32_t)((pix0 + ri * a.W + (m - ri * wi)) * K + vec * 8) * (uint32_t)sizeof(T);
+          const unsigned char* src = (is_w ? w_b : in_b) + (ok ? (is_w ? off_w : off_p) : 0u);
+          rq0[j] = *reinterpret_cast<const raw_t*>(src); if (!BF16) rq1[j] = *reinterpret_cast<const raw_t*>(src + 16);
+          const int sl = udiv_rcp(vec, a.kpv_rcp), col = vec * 8 - sl * Kp;
+          qsl[j] = ok ? sl : -1;
+          qdst[j] = is_w ? -(1 + row * KP + col) : m * KP + col;
+        }
+      }
+      raw_t w0[NIW], w1[NIW], p0[NIP], p1[NIP];
+      auto issue = [&](int p) {
+        if constexpr (RES) return;
+        const int kb = p * Kp + pv * 8;
+        const bool vk = pv < pvecs && kb < K;                       // (K is a multiple of 8: a vector is inside or outside)
+#pragma unroll
+        for (int j = 0; j < NIW; j++) {
+          const int row = j * prs + prow0;
+          const unsigned char* src = w_b + (vk && row < n_wrows ? (uint32_t)(row * K + kb) * (uint32_t)sizeof(T) : 0u);
+          w0[j] = *reinterpret_cast<const raw_t*>(src); if (!BF16) w1[j] = *reinterpret_cast<const raw_t*>(src + 16);
+        }
+#pragma unroll
+        for (int j = 0; j < NIP; j++) {
+          const int mm = j * prs + prow0, m = min(mm, n_in - 1), ri = row_of(m);
+          const uint32_t off = (uint32_t)((pix0 + ri * a.W + (m - ri * wi)) * K + kb) * (uint32_t)sizeof(T);
+          const unsigned char* src = in_b + (vk && mm < n_in ? off : 0u);
+          p0[j] = *reinterpret_cast<const raw_t*>(src); if (!BF16) p1[j] = *reinterpret_cast<const raw_t*>(src + 16);
+        }
+      };
+      auto park = [&](int p) {
+        if constexpr (RES) {
+#pragma unroll
+          for (int j = 0; j < NJ; j++)
+            if (qsl[j] == p) {
+              raw_t* d = qdst[j] < 0 ? reinterpret_cast<raw_t*>(w_s + (-1 - qdst[j])) : reinterpret_cast<raw_t*>(a_s + qdst[j]);
+              d[0] = rq0[j]; if (!BF16) d[1] = rq1[j];
+            }
+          return;
+        }
+        const bool vk = pv < pvecs && p * Kp + pv * 8 < K;          // weights beyond K are parked as ZEROS (the activation columns there
+#pragma unroll                                                        //  keep the previous pass's finite values: finite x 0)
+        for (int j = 0; j < NIW; j++) {
+          const int row = j * prs + prow0;
+          if (pv < pvecs && row < n_wrows) {
+            raw_t* d = reinterpret_cast<raw_t*>(w_s + row * KP + pv * 8);
+            d[0] = vk ? w0[j] : raw_t{}; if (!BF16) d[1] = vk ? w1[j] : raw_t{};
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < NIP; j++) {
+          const int m = j * prs + prow0;
+          if (vk && m < n_in) {
+            raw_t* d = reinterpret_cast<raw_t*>(a_s + m * KP + pv * 8);
+            d[0] = p0[j]; if (!BF16) d[1] = p1[j];
+          }
+        }
+      };
+      issue(0);
+      {
+        const int nv = PIN * EP * (int)sizeof(T) / 16;               // the whole [PIN][EP] tile: zeros = the depthwise conv's padding
+        for (int i = threadIdx.x; i < nv; i += MBF_THREADS) reinterpret_cast<u32x4*>(e_s)[i] = (u32x4){0, 0, 0, 0};
+      }
+      XSTAMP(2); park_weights(); XSTAMP(3);
+      park(0);
+      MSTAMP(1); XSTAMP(4);
+      __syncthreads();
+      MSTAMP(2); XSTAMP(5);
+      const int ntsh = ntiles <= 1 ? 0 : 32 - __builtin_clz(ntiles - 1);
+      const int nt = wave & ((1 << ntsh) - 1), grp = wave >> ntsh, ngrp = MBF_WAVES >> ntsh;
+      const int mtiles = (n_in + 15) >> 4, kspp = Kp / KSTEP;
+      constexpr int MAXMT = TS == 16 ? 7 : 5, KSPMAX = 3;            // m-tiles per wave, k-steps per pass (host-checked)
+      f32x4 acc[MAXMT];
+#pragma unroll
+      for (int i = 0; i < MAXMT; i++) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+      for (int p = 0; p < npass; p++) {
+        if (p + 1 < npass) issue(p + 1);                             // the next slice travels under this pass's MFMAs
+        if (nt < ntiles) {
+          raw_t wfr[KSPMAX];
+          const T* wrow = w_s + (nt * 16 + r) * KP + KLANE * g;
+#pragma unroll
+          for (int ks = 0; ks < KSPMAX; ks++) {
+            wfr[ks] = *reinterpret_cast<const raw_t*>(wrow + (ks < kspp ? ks * KSTEP : 0));
+            if (p * Kp + ks * KSTEP + KLANE * g >= K) wfr[ks] = raw_t{};     // k >= K (last slice): the weight is the zero, the activation column holds finite leftovers
+          }
+#pragma unroll
+          for (int i = 0; i < MAXMT; i++) {
+            const int mt = grp + i * ngrp;
+            if (mt < mtiles) {                                       // (wave-uniform)
+              const T* arow = a_s + min(mt * 16 + r, n_in - 1) * KP + KLANE * g;
+#pragma unroll
+              for (int ks = 0; ks < KSPMAX; ks++) {
+                if (ks < kspp) {                                     // (uniform)
+                  const raw_t xa = *reinterpret_cast<const raw_t*>(arow + ks * KSTEP);
+                  if constexpr (BF16) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wfr[ks]), __builtin_bit_cast(bf16x8, xa), acc[i], 0, 0, 0);
+                  else {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wfr[ks][q], xa[q], acc[i], 0, 0, 0);
+                  }
+                }
+              }
+            }
+          }
+        }
+        __syncthreads();                                             // every wave has read this slice
+        if (p + 1 < npass) { park(p + 1); __syncthreads(); }
+      }
+      // bias + swish -> the expanded tile (only pixels inside the image; the rest stays zero)
+      {
+        const int n = nt * 16 + 4 * g;
+        if (nt < ntiles && n < cc) {
+          const f32x4 bias = *reinterpret_cast<const f32x4*>(be_s + n);
+#pragma unroll
+          for (int i = 0; i < MAXMT; i++) {
+            const int m = (grp + i * ngrp) * 16 + r;
+            if (m < n_in) {
+              const int ri = row_of(m), pp_ = (r0 + ri) * PW + q0 + (m - ri * wi);
+              float vv[4];
+#pragma unroll
+              for (int q = 0; q < 4; q++) vv[q] = swish_t<BF16>(acc[i][q] + bias[q]);
+              V::store4(e_s, (int64_t)pp_ * EP + n, vv);
+            }
+          }
+        }
+      }
+      MSTAMP(3);
+      __syncthreads();
+      MSTAMP(4);
+    } else if (a.has_expand) {
       // rows = the expand-weight rows c0 .. c0 + 16*ntiles, then the tile pixels INSIDE the image (compact rows
       // m = ri * wi + ci of the rectangle [r0,r1) x [q0,q1) of the PW x PW tile): only those are staged and expanded;
       // the rest of the expanded tile is the zero padding of the depthwise conv and is written as zeros right here
@@ -230,12 +386,14 @@ __global__ __launch_bounds__(TS == 16 ? 1024 : 512) void mbf_kernel(MbfArgs a) {
       }
     }
   }
+  if constexpr (MP == 0) {
   MSTAMP(1); XSTAMP(4);
   __syncthreads();
   MSTAMP(2); XSTAMP(5);
+  }
 
   // ---- phase B: expand 1x1 + bias + swish -> e_s ----
-  if (a.has_expand) {
+  if (MP == 0 && a.has_expand) {
     // a wave takes TWO m-tiles per weight fragment (one LDS weight read feeds two MFMAs) and keeps
     // three k-steps of fragments in flight
     const int mpairs = (n_in + 31) >> 5;                           // pairs of 16-pixel m-tiles over the inside pixels
@@ -357,7 +515,7 @@ __global__ __launch_bounds__(TS == 16 ? 1024 : 512) void mbf_kernel(MbfArgs a) {
     MSTAMP(3);
     __syncthreads();
   }
-  MSTAMP(4);
+  if constexpr (MP == 0) { MSTAMP(4); }
 
   // ---- phase C: depthwise taps from LDS -> global, SE sums ----
   // A lane owns TWO horizontally adjacent output pixels: their kx windows overlap, so a row of
@@ -512,25 +670,48 @@ int mbf_max_inside(int H, int W, int k, int s, int pad_t, int pad_l, int ts) {
 
 int mbf_threads(int ts) { return ts == 16 ? 1024 : 512; }
 
-size_t mbf_lds_layout(int Cin, int CC, int k, int s, int bf16, int has_expand, int max_inside, int ts, MbfArgs* a) {
+// kp: input channels per pass of the multi-pass expand (0 or >= Cin: one pass, the whole K in LDS)
+size_t mbf_lds_layout(int Cin, int CC, int k, int s, int bf16, int has_expand, int max_inside, int ts, MbfArgs* a, int kp) {
   const size_t es = bf16 ? 2 : 4, pad = bf16 ? 8 : 4;
   const size_t pw = (size_t)(ts - 1) * s + k, pin = pw * pw;
   const size_t arows = (((size_t)std::min<int>(max_inside, (int)pin) + 31) / 32) * 32;   // phase B reads whole pairs of 16-row m-tiles
-  size_t in_bytes = has_expand ? arows * (Cin + pad) * es : 0;
-  in_bytes = std::max(in_bytes, (size_t)mbf_threads(ts) * 9 * 4);        // the tap-row hand-over of phase C lives there too
+  const bool mp = has_expand && kp > 0 && kp < Cin;
+  const size_t kcols = mp ? (size_t)kp : (size_t)Cin;
+  size_t in_bytes = has_expand ? arows * (kcols + pad) * es : 0;
+  // the tap-row hand-over of phase C lives there too (8x8 tiles: two halves of the workgroup; the multi-pass 16x16 form has none)
+  in_bytes = std::max(in_bytes, mp && ts == 16 ? (size_t)0 : (size_t)mbf_threads(ts) * 9 * 4);
   in_bytes = (in_bytes + 15) & ~(size_t)15;
   const size_t e_bytes = (std::max(pin * (CC + pad) * es, (size_t)16 * CC * 4) + 15) & ~(size_t)15;   // (phase D: [<= 16][CC] channel sums)
   const size_t w_bytes = (size_t)(k * k + 2) * CC * 4;                    // depthwise weights + the two bias vectors
-  const size_t we_bytes = has_expand ? (((size_t)CC * (Cin + pad) * es + 15) & ~(size_t)15) : 0;   // expand-weight chunk
+  const size_t we_bytes = has_expand ? (((size_t)CC * (kcols + pad) * es + 15) & ~(size_t)15) : 0;   // expand-weight chunk (one K slice of it)
   if (a) { a->off_e = in_bytes; a->off_we = in_bytes + e_bytes; a->off_w = a->off_we + we_bytes; a->lds_bytes = a->off_w + w_bytes; }
   return in_bytes + e_bytes + we_bytes + w_bytes;
 }
 
+// does a multi-pass plan fit the kernel's compile-time budgets (row batches per lane and pass, k-steps per pass, m-tiles per wave)?
+int mbf_mp_fits(int CC, int kp, int bf16, int max_inside, int ts) {
+  const int threads = mbf_threads(ts), waves = threads / 64, kstep = bf16 ? 32 : 16;
+  if (kp <= 0 || kp % kstep != 0 || kp / kstep > 3) return 0;
+  int vp = 1; while (vp < kp / 8) vp <<= 1;
+  const int prs = threads / vp, niw = ts == 16 ? 1 : 2, nip = ts == 16 ? 2 : 3;
+  const int ntiles = (CC + 15) / 16; int np2 = 1; while (np2 < ntiles) np2 <<= 1;
+  if (np2 > waves) return 0;
+  const int ngrp = waves / np2, mtiles = (max_inside + 15) / 16, maxmt = ts == 16 ? 7 : 5;
+  return ntiles * 16 <= niw * prs && max_inside <= nip * prs && (mtiles + ngrp - 1) / ngrp <= maxmt;
+}
+// ... and can the whole tile (weight rows + inside pixels, K / 8 vectors each) be held in six vectors per lane (MP = 2)?
+int mbf_mp_resident(int Cin, int CC, int max_inside, int ts) {
+  const long items = (long)(((CC + 15) / 16) * 16 + max_inside) * (Cin / 8);
+  return Cin % 8 == 0 && items <= 6L * mbf_threads(ts);
+}
+
 template <bool BF16, int KS, int S, int TS>
 static int prep_one() {
-  int rc = hipFuncSetAttribute(reinterpret_cast<const void*>(mbf_kernel<BF16, KS, S, TS, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024) == hipSuccess ? 0 : -1;
+  int rc = hipFuncSetAttribute(reinterpret_cast<const void*>(mbf_kernel<BF16, KS, S, TS, false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024) == hipSuccess ? 0 : -1;
+  rc |= hipFuncSetAttribute(reinterpret_cast<const void*>(mbf_kernel<BF16, KS, S, TS, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024) == hipSuccess ? 0 : -1;
+  rc |= hipFuncSetAttribute(reinterpret_cast<const void*>(mbf_kernel<BF16, KS, S, TS, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024) == hipSuccess ? 0 : -1;
 #ifdef HEP_WITH_FP8
-  if constexpr (BF16) rc |= hipFuncSetAttribute(reinterpret_cast<const void*>(mbf_kernel<true, KS, S, TS, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024) == hipSuccess ? 0 : -1;
+  if constexpr (BF16) rc |= hipFuncSetAttribute(reinterpret_cast<const void*>(mbf_kernel<true, KS, S, TS, true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024) == hipSuccess ? 0 : -1;
 #endif
   return rc;
 }
@@ -540,16 +721,16 @@ int mbf_prepare(void) {
          prep_one<true, 3, 1, 16>() | prep_one<true, 5, 1, 16>() | prep_one<false, 3, 1, 16>() | prep_one<false, 5, 1, 16>();
 }
 
-template <bool BF16, bool F8>
+template <bool BF16, bool F8, int MP>
 static void launch_mbf_t(const MbfArgs& a, dim3 grid, hipStream_t s) {
   if (a.ts == 16) {       // stride 1 only (the planner never asks for 16x16 tiles on a stride-2 layer)
-    if (a.k == 3) hipLaunchKernelGGL((mbf_kernel<BF16, 3, 1, 16, F8>), grid, dim3(1024), a.lds_bytes, s, a);
-    else hipLaunchKernelGGL((mbf_kernel<BF16, 5, 1, 16, F8>), grid, dim3(1024), a.lds_bytes, s, a);
+    if (a.k == 3) hipLaunchKernelGGL((mbf_kernel<BF16, 3, 1, 16, F8, MP>), grid, dim3(1024), a.lds_bytes, s, a);
+    else hipLaunchKernelGGL((mbf_kernel<BF16, 5, 1, 16, F8, MP>), grid, dim3(1024), a.lds_bytes, s, a);
   }
-  else if (a.k == 3 && a.s == 1) hipLaunchKernelGGL((mbf_kernel<BF16, 3, 1, 8, F8>), grid, dim3(512), a.lds_bytes, s, a);
-  else if (a.k == 3 && a.s == 2) hipLaunchKernelGGL((mbf_kernel<BF16, 3, 2, 8, F8>), grid, dim3(512), a.lds_bytes, s, a);
-  else if (a.k == 5 && a.s == 1) hipLaunchKernelGGL((mbf_kernel<BF16, 5, 1, 8, F8>), grid, dim3(512), a.lds_bytes, s, a);
-  else hipLaunchKernelGGL((mbf_kernel<BF16, 5, 2, 8, F8>), grid, dim3(512), a.lds_bytes, s, a);
+  else if (a.k == 3 && a.s == 1) hipLaunchKernelGGL((mbf_kernel<BF16, 3, 1, 8, F8, MP>), grid, dim3(512), a.lds_bytes, s, a);
+  else if (a.k == 3 && a.s == 2) hipLaunchKernelGGL((mbf_kernel<BF16, 3, 2, 8, F8, MP>), grid, dim3(512), a.lds_bytes, s, a);
+  else if (a.k == 5 && a.s == 1) hipLaunchKernelGGL((mbf_kernel<BF16, 5, 1, 8, F8, MP>), grid, dim3(512), a.lds_bytes, s, a);
+  else hipLaunchKernelGGL((mbf_kernel<BF16, 5, 2, 8, F8, MP>), grid, dim3(512), a.lds_bytes, s, a);
 }
 void launch_mbf(const MbfArgs& a_, hipStream_t s) {
   MbfArgs a = a_;
@@ -566,8 +747,10 @@ void launch_mbf(const MbfArgs& a_, hipStream_t s) {
   a.chunks = chunks; a.tiles_x = (a.Wo + a.ts - 1) / a.ts;
   a.chunks_rcp = rcp_u32(chunks); a.tiles_x_rcp = rcp_u32(a.tiles_x); a.gx_rcp = rcp_u32(grid.x);
 #ifdef HEP_WITH_FP8
-  if (a.bf16 && a.fp8) { launch_mbf_t<true, true>(a, grid, s); return; }
+  if (a.bf16 && a.fp8) { launch_mbf_t<true, true, 0>(a, grid, s); return; }
 #endif
-  if (a.bf16) launch_mbf_t<true, false>(a, grid, s);
-  else launch_mbf_t<false, false>(a, grid, s);
+  const int mp = a.has_expand && a.npass > 1 ? (a.mp_resident ? 2 : 1) : 0;
+  a.vk_rcp = rcp_u32((uint32_t)std::max(1, a.Cin >> 3)); a.kpv_rcp = rcp_u32((uint32_t)std::max(1, a.kp >> 3));
+  if (a.bf16) { if (mp == 2) launch_mbf_t<true, false, 2>(a, grid, s); else if (mp == 1) launch_mbf_t<true, false, 1>(a, grid, s); else launch_mbf_t<true, false, 0>(a, grid, s); }
+  else { if (mp == 2) launch_mbf_t<false, false, 2>(a, grid, s); else if (mp == 1) launch_mbf_t<false, false, 1>(a, grid, s); else launch_mbf_t<false, false, 0>(a, grid, s); }
 }

@@ -453,6 +453,8 @@ ALT_PLANS = [
     ({"HEP_MBF_TS": "8"}, lambda ks: not any("mbf_kernel" in y and y.endswith(", 16>") for _, y in ks)),
     ({"HEP_MBF": "none", "HEP_DWLDS": "0"}, lambda ks: not any("mbf_kernel" in y for _, y in ks)),
     ({"HEP_DWLDS": "1", "HEP_MBF": "none"}, lambda ks: all(n.endswith(".dw") for n, y in ks if "mbf_kernel" in y) and any("mbf_kernel" in y for _, y in ks)),
+    ({"HEP_MBF_MP": "force"}, lambda ks: sum(y.endswith(", false, 1>") for _, y in ks if "mbf_kernel" in y) >= 8),      # multi-pass fronts (K staged in slices) wherever they exist
+    ({"HEP_MBF_MP": "force", "HEP_MBF_MP_RES": "1"}, lambda ks: sum(y.endswith(", false, 2>") for _, y in ks if "mbf_kernel" in y) >= 8),      # ... with the whole tile requested at kernel start and held in registers
     ({"HEP_LANES": "2"}, None),
     ({"HEP_CHAIN": "0"}, lambda ks: not any("chain_kernel" in y or "sep_kernel<false, 2" in y for _, y in ks)),
     ({"HEP_CHAIN": "1"}, lambda ks: any("sep_kernel<false, 2" in y for _, y in ks) and not any("chain_kernel" in y for _, y in ks)),
@@ -503,6 +505,16 @@ def test_alternative_plans_keep_parity(api, env, planned, monkeypatch):
     for a, b in zip(out[0], ref[0]):
         assert (a.cpu() - b).abs().max().item() <= 1e-3
     s.close()
+
+
+def test_default_fp32_plan_uses_multi_pass_fronts(api):
+    """fp32 sessions at batch 16: the fronts of the 16x16 / 8x8 maps run the multi-pass expand (K staged in slices) so that their
+    workgroups fit the GPU in one round - 16x16 tiles on blocks 9 and 10, two workgroups per CU on the 8x8 maps."""
+    s = api["Session"](api["sd"](0, 4), 0, 256, 16, "fp32")
+    plan = dict(_plan_syms(s, 16))
+    s.close()
+    assert plan["b9.front"] == "mbf_kernel<false, 5, 1, 16, false, 1>" and plan["b10.front"] == plan["b9.front"], plan
+    assert all(plan[f"b{i}.front"].endswith(", 8, false, 1>") for i in (12, 13, 14, 15)), plan
 
 
 def test_default_fp32_plan_runs_its_chains_in_lds(api):
