@@ -537,15 +537,20 @@ struct Planner {
     if (want && !(mode && !strcmp(mode, "none")))
       for (int cand : {64, 32, 16})
         if (mbf_lds_layout(b.cin, std::min(cand, b.expand ? cand : b.cexp), b.k, b.stride, s->dtype, b.expand, max_in, ts, nullptr) <= 159 * 1024) { CC = cand; break; }
-    // fp32 sessions (HEP_MBF_MP=0 disables, =1 also for bf16): the tile / channel chunk / K-slice plan with the fewest ROUNDS of
-    // workgroups.  With the whole K staged at once an fp32 front needs twice the LDS of the bf16 one: the 16x16 tile of blocks 9,
+    // The tile / channel chunk / K-slice plan with the fewest ROUNDS of workgroups (HEP_MBF_MP=0 disables, =2 lifts the bf16
+    // restriction below, =force takes the multi-pass form wherever it exists).  With the whole K staged at once an fp32 front needs twice the LDS of the bf16 one: the 16x16 tile of blocks 9,
     // 10 fell back to 8x8 (704 workgroups on 256 CUs: three rounds, 37 us against 17 us in bf16), the 8x8 maps kept one workgroup
     // of 146 KB per CU where 288 want to be resident (two rounds).  The multi-pass expand (k_mbf.hip, MP) stages K in slices and
     // gives fp32 the workgroup counts of the bf16 plan.
     {
       const char* e = getenv("HEP_MBF_MP");
       const bool force = e && !strcmp(e, "force");                  // parity runs: the multi-pass form wherever it exists, whatever the rounds
-      const bool mp_on = e ? (force || (atoi(e) != 0 && (s->dtype == 0 || atoi(e) == 1))) : s->dtype == 0;
+      const bool mp_on = e ? (force || atoi(e) != 0) : true;
+      // A pass costs ~1 us of phase changes and the wider chunk a longer depthwise phase, so one round saved out of three does not
+      // pay (phi 3 blocks 9-12, bf16: 3 -> 2 rounds, 23.6 -> 26.4 us): the multi-pass plan must at least HALVE the rounds.  bf16
+      // sessions additionally keep plans of up to two rounds (HEP_MBF_MP=2 lifts that): measured only where the gain is large -
+      // phi 3 @ 512 b8 blocks 14-17 (7 -> 2 rounds) 47 -> 38 us, blocks 19-23 26.5 -> 18.9 us, 4.65k -> 4.87k frames/s.
+      const long min_old_rounds = (s->dtype == 0 || (e && atoi(e) == 2)) ? 2 : 3;
       if (CC && b.expand && mp_on && s->dtype != 2) {
         struct Cand { int ts, CC, npass, kp; long rounds; size_t lds; };
         const int kstep = s->dtype ? 32 : 16, ksteps = (b.cin + kstep - 1) / kstep;
@@ -567,7 +572,7 @@ struct Planner {
               if (lds > 159 * 1024) continue;
               const Cand c{ts_, cc_, np_, kp_, rounds_of(ts_, cc_, lds), lds};
               // fewer rounds first; then fewer passes (two barriers each); then the wider chunk
-              if (c.rounds < best.rounds || (force && best.npass == 1) ||
+              if ((best.npass == 1 && 2 * c.rounds <= best.rounds && best.rounds >= min_old_rounds) || (best.npass > 1 && c.rounds < best.rounds) || (force && best.npass == 1) ||
                   (c.rounds == best.rounds && best.npass > 1 && (c.npass < best.npass || (c.npass == best.npass && c.CC > best.CC)))) best = c;
             }
         }
