@@ -718,7 +718,9 @@ int hep_kernel_symbol(const hep_handle* h, int i, const char** symbol) try {
     case OP_STEM: if (o.stem.mfma) snprintf(tmp, sizeof tmp, "stem_kernel<%s, %d>", t, (o.stem.Cout + 15) / 16);
                   else snprintf(tmp, sizeof tmp, "stem_valu_kernel<%s>", t);
                   break;
-    case OP_PW: snprintf(tmp, sizeof tmp, "pw_gemm_kernel<%d, %d, %d, %d, %d, %d>", prec, o.pw.MT, o.pw.NT, o.pw.mode, o.pw.act == ACT_SWISH ? 1 : 0, pw_se_variant(o.pw)); break;
+    case OP_PW: { const int sev = pw_se_variant(o.pw);
+                  const bool w8 = o.pw.nwv == 8 && prec == 0 && o.pw.mode == 2 && o.pw.act != ACT_SWISH && (sev == 0 || sev == 3) && o.pw.NT <= 2;
+                  snprintf(tmp, sizeof tmp, w8 ? "pw_gemm_kernel<%d, %d, %d, %d, %d, %d, 8>" : "pw_gemm_kernel<%d, %d, %d, %d, %d, %d>", prec, o.pw.MT, o.pw.NT, o.pw.mode, o.pw.act == ACT_SWISH ? 1 : 0, sev); break; }
     case OP_DW: snprintf(tmp, sizeof tmp, "dw_kernel<%s, %d, %d, %d>", t, o.dw.k, o.dw.s, o.dw.TW); break;
     case OP_POOL: snprintf(tmp, sizeof tmp, "pool_kernel<%s>", t); break;
     case OP_PWG: snprintf(tmp, sizeof tmp, "pw_group_kernel<%s>", t); break;

@@ -60,6 +60,7 @@ struct PwArgs {
   int act, bf16, MT, NT;
   int fp8; const float* wscale; float a_scale;   // fp8 operands (k_pw_impl.h): W is e4m3 [tilesN*16][K], per-row scales, per-tensor activation scale
   int mode;            // wave arrangement inside a workgroup: 0 along M, 1 along N, 2 split-K (k_pw.hip)
+  int nwv;             // waves per workgroup: 4; 8 for the split-K project convs of fp32 sessions (k_pw_impl.h)
   int chunksN; uint32_t chunksN_rcp;   // filled by launch_pw_prec: workgroups along N and rcp_u32() of that
   unsigned long long* trace_buf;   // profiling builds (-DHEP_PW_TRACE): stamps of this launch go here
 };

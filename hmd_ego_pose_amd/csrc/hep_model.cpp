@@ -309,6 +309,13 @@ struct Planner {
         const char* e = getenv("HEP_PW_MT2");
         if (pmode != 0 && strips >= 8 && !(e && atoi(e) == 0)) { pMT = 2; pNT = std::min(pNT, 4); }
         if (pmode == 2) pNT = std::min(pNT, std::max(1, getenv("HEP_PW_NT2") ? atoi(getenv("HEP_PW_NT2")) : 2));
+        // one more n-tile per wave where that brings the launch from two rounds of workgroups to one (the last project conv of
+        // phi 0: 1152 -> 320 on the 8x8 maps, 32 x 10 = 320 workgroups with two n-tiles, 32 x 7 = 224 with three); HEP_PW_NT3=0 disables
+        if (pmode == 2 && !(getenv("HEP_PW_NT3") && atoi(getenv("HEP_PW_NT3")) == 0)) {
+          const int64_t mblocks = (strips + pMT - 1) / pMT;
+          auto wgs = [&](int nt) { return mblocks * ((tilesN + nt - 1) / nt); };
+          if (wgs(pNT) > 256 && wgs(pNT) <= 512 && pNT < 8 && wgs(pNT + 1) <= 256) pNT++;
+        }
       }
     }
     // Squeeze-excite: finished in this GEMM's prologue (no launch) while the K x sq expand-FC matrix re-read by every
@@ -338,6 +345,8 @@ struct Planner {
     Op& o = s->ops[op];
     o.pw.K = K; o.pw.N = N; o.pw.tilesN = tilesN; o.pw.HW = HW; o.pw.act = act; o.pw.bf16 = s->dtype;
     o.pw.mode = pmode; o.pw.MT = pMT; o.pw.NT = pNT;
+    // fp32 split-K GEMMs deep enough for eight K slices of two load batches each (HEP_PW_W8=0: four waves as before)
+    o.pw.nwv = (s->dtype == 0 && pmode == 2 && pNT <= 2 && K >= (getenv("HEP_PW_W8_MINK") ? atoi(getenv("HEP_PW_W8_MINK")) : 512) && !(getenv("HEP_PW_W8") && atoi(getenv("HEP_PW_W8")) == 0)) ? 8 : 4;
     tref(op, F_PW_A, in_t, false); tref(op, F_PW_OUT, out_t, true);     // (reads[0] is the GEMM's activation operand: fp8 calibration)
     if (quant && s->dtype == 2) {     // fp8 session: e4m3 weights, one scale per output channel behind the BN fold
       std::vector<float> sc;

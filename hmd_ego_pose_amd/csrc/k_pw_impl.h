@@ -67,8 +67,14 @@ extern unsigned long long* g_pw_trace_host;     // device buffer (k_pw.hip); tra
 #define PSTAMP(i)
 #endif
 
-template <int PREC, int MT, int NT, int MODE, int ACT, int SEV>
-__global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
+// NWV: waves per workgroup.  4 everywhere except the split-K project convs of fp32 sessions (MODE 2, SEV 0 / 3), which run 8:
+// their K loop is the exact-fp32 MFMAs (128 MAC per clock and CU: 3.8 us of a wave's 11.8 us at K = 1152) IN SERIES with the
+// fragment loads - one wave per SIMD has nothing to overlap them with.  Eight K slices halve a wave's MFMA chain and put a
+// second wave on every SIMD.  (bf16: measured slower in round 3, 11 us against 9 - its MFMAs are 16 x cheaper.)
+template <int PREC, int MT, int NT, int MODE, int ACT, int SEV, int NWV = 4>
+__global__ __launch_bounds__(NWV * 64) void pw_gemm_kernel(PwArgs a) {
+  static_assert(NWV == 4 || (MODE == 2 && (SEV == 0 || SEV == 3)), "eight waves: split-K with the scale copied from se_finish_kernel only");
+  constexpr int NTHR = NWV * 64;
   constexpr bool BF16 = PREC != 0, F8 = PREC == 2;
 #ifdef HEP_PW_TRACE
   unsigned long long stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -96,7 +102,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
   else {
     m0 = mblk * (16 * MT); ntile0 = nchunk * NT;
     constexpr int UU = BF16 ? 2 : HEP_PW_UF32;
-    const int steps = (K + F::KSTEP - 1) / F::KSTEP, per = ((steps + 3) / 4 + UU - 1) / UU * UU;   // slices start on whole load batches
+    const int steps = (K + F::KSTEP - 1) / F::KSTEP, per = ((steps + NWV - 1) / NWV + UU - 1) / UU * UU;   // slices start on whole load batches
     kbeg = min(K, wave * per * F::KSTEP); kend = min(K, (wave + 1) * per * F::KSTEP);
   }
 
@@ -167,12 +173,12 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
     const int nimg = udiv_f(mlast, a.HW, hw_inv) - img0 + 1;
     const float* sc_g = a.se_scale + (int64_t)img0 * K;
     const int nsc = nimg * K;                                             // K is a multiple of 8
-    for (int i0 = threadIdx.x * 4; i0 < nsc; i0 += 256 * 4 * 4) {         // four vectors in flight per lane: K <= 4096 is one round trip
+    for (int i0 = threadIdx.x * 4; i0 < nsc; i0 += NTHR * 4 * 4) {        // four vectors in flight per lane: K <= 4096 is one round trip
       f32x4 v[4];
 #pragma unroll
-      for (int q = 0; q < 4; q++) v[q] = *reinterpret_cast<const f32x4*>(sc_g + min(i0 + q * 1024, nsc - 4));
+      for (int q = 0; q < 4; q++) v[q] = *reinterpret_cast<const f32x4*>(sc_g + min(i0 + q * NTHR * 4, nsc - 4));
 #pragma unroll
-      for (int q = 0; q < 4; q++) if (i0 + q * 1024 < nsc) *reinterpret_cast<f32x4*>(se_s + i0 + q * 1024) = v[q];
+      for (int q = 0; q < 4; q++) if (i0 + q * NTHR * 4 < nsc) *reinterpret_cast<f32x4*>(se_s + i0 + q * NTHR * 4) = v[q];
     }
     __syncthreads();
   } else if constexpr (SE) {
@@ -367,8 +373,8 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
   else if (kk < kend) compute2(0, kk);
 
   PSTAMP(3);
-  if (MODE == 2) {   // meet the four K-slices in LDS; wave w finishes n-tiles j = w, w+4, ...
-    __shared__ f32x4 red[4][MT][NT][64];
+  if (MODE == 2) {   // meet the K-slices in LDS (fixed order); wave w < 4 finishes n-tiles j = w, w+4, ...
+    __shared__ f32x4 red[NWV][MT][NT][64];
 #pragma unroll
     for (int i = 0; i < MT; i++)
 #pragma unroll
@@ -378,7 +384,11 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
     for (int i = 0; i < MT; i++)
 #pragma unroll
       for (int j = 0; j < NT; j++)
-        if ((j & 3) == wave) acc[i][j] = (red[0][i][j][lane] + red[1][i][j][lane]) + (red[2][i][j][lane] + red[3][i][j][lane]);
+        if ((j & 3) == wave) {
+          f32x4 sum = (red[0][i][j][lane] + red[1][i][j][lane]) + (red[2][i][j][lane] + red[3][i][j][lane]);
+          if constexpr (NWV == 8) sum += (red[4][i][j][lane] + red[5][i][j][lane]) + (red[6][i][j][lane] + red[7][i][j][lane]);
+          acc[i][j] = sum;
+        }
   }
 
   PSTAMP(4);
@@ -414,7 +424,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
   }
 #ifdef HEP_PW_TRACE
   PSTAMP(5);
-  if (a.trace_buf && lane == 0) {
+  if (a.trace_buf && lane == 0 && wave < 4) {
     unsigned long long* o = a.trace_buf + ((size_t)blockIdx.x * 4 + wave) * 8;
     for (int i = 0; i < 6; i++) o[i] = stamps[i];
   }
@@ -426,6 +436,13 @@ static void launch_nt(const PwArgs& a, dim3 grid, hipStream_t s) {
   // dynamic LDS of the squeeze-excite prologue: scale [se_nimg][K] | hidden [sqp] | helper-group row sums [<= 256]
   const size_t lds = a.sq > 0 ? ((size_t)a.se_nimg * a.K + a.sqp + 256 + a.sqp) * sizeof(float) : 0;
   const int sev = pw_se_variant(a);
+  if constexpr (PREC == 0 && MODE == 2) {
+    if (a.nwv == 8 && a.act != ACT_SWISH && (sev == 0 || sev == 3) && a.NT <= 2) {
+      if (sev == 3) { if (a.NT == 2) hipLaunchKernelGGL((pw_gemm_kernel<PREC, MT, 2, MODE, ACT_NONE, 3, 8>), grid, dim3(512), lds, s, a); else hipLaunchKernelGGL((pw_gemm_kernel<PREC, MT, 1, MODE, ACT_NONE, 3, 8>), grid, dim3(512), lds, s, a); }
+      else { if (a.NT == 2) hipLaunchKernelGGL((pw_gemm_kernel<PREC, MT, 2, MODE, ACT_NONE, 0, 8>), grid, dim3(512), 0, s, a); else hipLaunchKernelGGL((pw_gemm_kernel<PREC, MT, 1, MODE, ACT_NONE, 0, 8>), grid, dim3(512), 0, s, a); }
+      return;
+    }
+  }
   switch (a.NT) {
 #define CASE(n) case n: if (a.act == ACT_SWISH) hipLaunchKernelGGL((pw_gemm_kernel<PREC, MT, n, MODE, ACT_SWISH, 0>), grid, dim3(256), 0, s, a); \
                 else if (sev == 0) hipLaunchKernelGGL((pw_gemm_kernel<PREC, MT, n, MODE, ACT_NONE, 0>), grid, dim3(256), 0, s, a); \
