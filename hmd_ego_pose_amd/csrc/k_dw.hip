@@ -155,6 +155,10 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs a) {
 }
 
 // ---- the VALU form (kept: faster than the MFMA form on 32-channel stems, see launch_stem) ----
+// (round 4: a two-pixels-per-lane form for W-contiguous inputs - the five input columns of a pixel pair as one aligned 16-byte
+//  load + one 4-byte load per row and channel, 18 load instructions per pair instead of 54 - measured SLOWER: 18.7 us against
+//  15.9 us in bf16, 34 us against 19 us in fp32 at phi 0 b16; 114-126 registers = four waves per SIMD instead of seven, and the
+//  kernel is not short of load slots: 29 MB in 16 us with ~5 us of fma / swish issue per SIMD is latency hiding, i.e. waves)
 // One lane = one output pixel: its 27 inputs are loaded once (zero outside the image, branch-free)
 // and reused for every group of 8 output channels; the weights of a group are the same for the whole
 // wave, so they arrive through the scalar cache and feed the FMAs as scalar operands.

@@ -619,6 +619,9 @@ __global__ __launch_bounds__(TS == 16 ? 1024 : 512) void mbf_kernel(MbfArgs a) {
         for (int c = 0; c < 4; c++) { cs[c] += s0[c]; cs[4 + c] += s1[c]; }
       }
     }
+    // (round 4: requesting the reduce weights at kernel start - their addresses depend on nothing the kernel computes, at the end
+    //  they are a dependent L2 round trip - measured SLOWER: 48.7k against 49.6k frames/s in bf16, 24.75k against 24.94k in fp32,
+    //  three interleaved runs each; eight more live registers through every phase cost more than the round trip)
     float* hrow = a.hpart + ((int64_t)b * gridDim.x + bxl) * a.sqp;         // gridDim.x = tiles * chunks
     for (int j = threadIdx.x >> 3; j < ((a.sq + 63) & ~63); j += MBF_THREADS / 8) {
       float dot = 0.f;
