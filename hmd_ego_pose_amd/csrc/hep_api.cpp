@@ -720,14 +720,15 @@ int hep_kernel_symbol(const hep_handle* h, int i, const char** symbol) try {
                   break;
     case OP_PW: { const int sev = pw_se_variant(o.pw);
                   const bool w8 = o.pw.nwv == 8 && prec == 0 && o.pw.mode == 2 && o.pw.act != ACT_SWISH && (sev == 0 || sev == 3) && o.pw.NT <= 2;
-                  snprintf(tmp, sizeof tmp, w8 ? "pw_gemm_kernel<%d, %d, %d, %d, %d, %d, 8>" : "pw_gemm_kernel<%d, %d, %d, %d, %d, %d>", prec, o.pw.MT, o.pw.NT, o.pw.mode, o.pw.act == ACT_SWISH ? 1 : 0, sev); break; }
+                  // (the names rocprofv3 prints: bench.py looks the PMC traffic of a device function up by this string)
+                  snprintf(tmp, sizeof tmp, "pw_gemm_kernel<%d, %d, %d, %d, %d, %d, %d>", prec, o.pw.MT, o.pw.NT, o.pw.mode, o.pw.act == ACT_SWISH ? 1 : 0, sev, w8 ? 8 : 4); break; }
     case OP_DW: snprintf(tmp, sizeof tmp, "dw_kernel<%s, %d, %d, %d>", t, o.dw.k, o.dw.s, o.dw.TW); break;
     case OP_POOL: snprintf(tmp, sizeof tmp, "pool_kernel<%s>", t); break;
     case OP_PWG: snprintf(tmp, sizeof tmp, "pw_group_kernel<%s>", t); break;
     case OP_CHAIN: snprintf(tmp, sizeof tmp, "chain_kernel<%s, %s>", o.chain.bf16 ? "true" : "false", o.chain.stream_w ? "true" : "false"); break;
     case OP_SE: snprintf(tmp, sizeof tmp, "se_finish_kernel<%s>", t); break;
-    case OP_MBF: if (o.mbf.has_expand && o.mbf.npass > 1) snprintf(tmp, sizeof tmp, "mbf_kernel<%s, %d, %d, %d, false, %d>", t, o.mbf.k, o.mbf.s, o.mbf.ts, o.mbf.mp_resident ? 2 : 1);      // (multi-pass expand)
-                 else snprintf(tmp, sizeof tmp, "mbf_kernel<%s, %d, %d, %d>", t, o.mbf.k, o.mbf.s, o.mbf.ts);
+    case OP_MBF: snprintf(tmp, sizeof tmp, "mbf_kernel<%s, %d, %d, %d, %s, %d>", t, o.mbf.k, o.mbf.s, o.mbf.ts, o.mbf.fp8 ? "true" : "false",
+                          o.mbf.has_expand && o.mbf.npass > 1 ? (o.mbf.mp_resident ? 2 : 1) : 0);      // (last argument: 1 / 2 = multi-pass expand)
                  break;
     case OP_SBF: snprintf(tmp, sizeof tmp, "sbf_kernel<%s>", t); break;
     case OP_XBF: { const int sp = xbf_specialised(o.xbf);

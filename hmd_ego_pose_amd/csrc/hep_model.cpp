@@ -309,9 +309,10 @@ struct Planner {
         const char* e = getenv("HEP_PW_MT2");
         if (pmode != 0 && strips >= 8 && !(e && atoi(e) == 0)) { pMT = 2; pNT = std::min(pNT, 4); }
         if (pmode == 2) pNT = std::min(pNT, std::max(1, getenv("HEP_PW_NT2") ? atoi(getenv("HEP_PW_NT2")) : 2));
-        // one more n-tile per wave where that brings the launch from two rounds of workgroups to one (the last project conv of
-        // phi 0: 1152 -> 320 on the 8x8 maps, 32 x 10 = 320 workgroups with two n-tiles, 32 x 7 = 224 with three); HEP_PW_NT3=0 disables
-        if (pmode == 2 && !(getenv("HEP_PW_NT3") && atoi(getenv("HEP_PW_NT3")) == 0)) {
+        // fp32 sessions: one more n-tile per wave where that brings the launch from two rounds of workgroups to one (the last
+        // project conv of phi 0: 1152 -> 320 on the 8x8 maps, 32 x 10 = 320 workgroups with two n-tiles, 32 x 7 = 224 with three:
+        // fp32 one batch -5 us; bf16 -2 us = inside the run-to-run spread, its plan stays as it was).  HEP_PW_NT3=0 / 1 overrides.
+        if (pmode == 2 && (getenv("HEP_PW_NT3") ? atoi(getenv("HEP_PW_NT3")) != 0 : s->dtype == 0)) {
           const int64_t mblocks = (strips + pMT - 1) / pMT;
           auto wgs = [&](int nt) { return mblocks * ((tilesN + nt - 1) / nt); };
           if (wgs(pNT) > 256 && wgs(pNT) <= 512 && pNT < 8 && wgs(pNT + 1) <= 256) pNT++;

@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Would split-bf16 matrix products keep an fp32-storage session inside the 1e-3 parity bound?  (TEST INFRASTRUCTURE; not a pytest file)
+
+    python tests/precision_bf16x3.py [phi size] > profiles/r04/bf16x3_emulation.txt
+
+The exact-fp32 MFMA (v_mfma_f32_16x16x4_f32) runs at 1/16 of the bf16 rate: 137 us of matrix pipe per batch-16 step at phi 0 even
+perfectly spread over the chip.  This script replaces every pointwise (1x1) product of the CPU oracle's folded
+network by its split-bf16 emulation - activations and weights stay fp32, only the PRODUCT is formed from bf16 pieces with fp32
+accumulation - and reports the distance of the five heads and of the decoded pose (ADD, as bench.py's add_vs_ref) from the fp32 oracle:
+  x3    x = xh + xl, w = wh + wl (bf16 each); xh.wh + xh.wl + xl.wh            three bf16 MFMAs per product
+  x4    ... + xl.wl                                                           four
+  x3w   weights exact (a three-way split), activations xh + xl                five MFMAs, six bytes per weight
+Result (phi 0 @ 256, 4 seeded frames): x3 1.29e-3 on the regression head - over the 1e-3 bound; rejected.
+"""
+import math
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch, torch.nn.functional as F
+from scipy.spatial.transform import Rotation
+from hmd_ego_pose_amd.weights import seeded_state_dict
+from oracle import decode_ref as D, efficientpose_ref as R
+torch.set_num_threads(8)
+phi, size, nf = int(sys.argv[1]) if len(sys.argv)>1 else 0, int(sys.argv[2]) if len(sys.argv)>2 else 256, 4
+sd = seeded_state_dict(phi, 0)
+rng = np.random.Generator(np.random.PCG64(99))
+x = torch.from_numpy(rng.standard_normal((nf, 3, size, size)).astype(np.float32))
+cam = np.array([[480, 480, 128, 128, 1000, 1.0]] * nf, np.float32)
+pts = (rng.standard_normal((1000, 3)) * np.array([40.0, 25.0, 60.0])).astype(np.float32)
+ref = R.forward(sd, x, phi)
+_, reg, cls, rot, trn, hand = ref
+_, t_anchors = D.anchors_for_size(size)
+t_ref = D.decode_translation(t_anchors, trn.numpy(), cam)
+idx = cls[:, :, 0].argmax(dim=1).numpy()
+pick = lambda v: np.stack([v[i, idx[i]] for i in range(nf)])
+def add_mm(g_rot, g_trn):
+    g_t = D.decode_translation(t_anchors, g_trn.numpy(), cam)
+    out = []
+    for i in range(nf):
+        R0 = Rotation.from_rotvec(pick(rot.numpy())[i] * math.pi).as_matrix()
+        R1 = Rotation.from_rotvec(pick(g_rot.numpy())[i] * math.pi).as_matrix()
+        p0 = pts @ R0.T + pick(t_ref)[i]; p1 = pts @ R1.T + pick(g_t)[i]
+        out.append(np.linalg.norm(p0 - p1, axis=1).mean())
+    return float(np.mean(out))
+q = R.q_bf16
+def split(t):
+    hi = q(t); lo = q(t - hi); return hi, lo
+mode = {"m": "x3"}
+def pw(self, xx, w, bias, tag=None):
+    xh, xl = split(xx); wh, wl = split(w)
+    if mode["m"] == "x3":      # hi*hi + hi*lo + lo*hi, fp32 accumulate
+        y = F.conv2d(xh, wh) + (F.conv2d(xh, wl) + F.conv2d(xl, wh))
+    elif mode["m"] == "x3w":   # weights exact (3-way split), activations hi+lo: x(hi+lo) * w
+        y = F.conv2d(xh + xl, w)
+    elif mode["m"] == "x4":
+        y = F.conv2d(xh, wh) + (F.conv2d(xh, wl) + F.conv2d(xl, wh)) + F.conv2d(xl, wl)
+    else:
+        y = F.conv2d(xx, w)
+    return y if bias is None else y + bias.view(1, -1, 1, 1)
+R._Emu.pw = pw
+for m in ("fp32", "x3", "x4", "x3w"):
+    mode["m"] = m
+    g = R.forward_emulated(sd, x, phi, q_act=None, q_w=None)
+    errs = [float((a - b).abs().max()) for a, b in zip(g[1:], ref[1:])]
+    print(m, "max abs err reg/cls/rot/trn/hand", ["%.2e" % e for e in errs], "ADD mm %.4f" % add_mm(g[3], g[4]))

@@ -450,7 +450,7 @@ def _plan_syms(s, batch):
 # (csrc/hep_model.cpp reads them with a plain getenv), so a case that silently re-tested the default plan would fail here
 ALT_PLANS = [
     ({"HEP_MBF": "all"}, lambda ks: any(n == "b3.front" for n, _ in ks) and any(n == "b0.front" for n, _ in ks)),
-    ({"HEP_MBF_TS": "8"}, lambda ks: not any("mbf_kernel" in y and y.endswith(", 16>") for _, y in ks)),
+    ({"HEP_MBF_TS": "8"}, lambda ks: not any("mbf_kernel" in y and ", 16, " in y for _, y in ks)),
     ({"HEP_MBF": "none", "HEP_DWLDS": "0"}, lambda ks: not any("mbf_kernel" in y for _, y in ks)),
     ({"HEP_DWLDS": "1", "HEP_MBF": "none"}, lambda ks: all(n.endswith(".dw") for n, y in ks if "mbf_kernel" in y) and any("mbf_kernel" in y for _, y in ks)),
     ({"HEP_MBF_MP": "force"}, lambda ks: sum(y.endswith(", false, 1>") for _, y in ks if "mbf_kernel" in y) >= 8),      # multi-pass fronts (K staged in slices) wherever they exist

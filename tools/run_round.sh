@@ -22,4 +22,10 @@ python tools/conc_profile.py > $T/conc.txt 2>&1
 tools/prof_bench.sh ${1}1 $2
 EXTRA_BENCH="--phi 3 --size 512 --batch 8" tools/prof_bench.sh ${1}p3 $2
 python tools/conc_profile.py 8 bf16 3 512 > $T/conc_phi3.txt 2>&1
+# fp32 sessions - the precision inside the 0.1 mm ADD bound: kernel stats, PMC, concurrent cost, per-launch plan
+EXTRA_BENCH="--precision fp32" tools/prof_bench.sh ${1}f32 $2
+python tools/conc_profile.py 16 fp32 > $T/conc_fp32.txt 2>&1
+python tools/plan.py 0 256 16 fp32 > $T/plan_fp32.txt 2>&1
+python tools/plan.py 0 256 16 bf16 > $T/plan_bf16.txt 2>&1
+python tools/plan.py 3 512 8 bf16 > $T/plan_phi3.txt 2>&1
 tools/mfma_util.sh ${1}1

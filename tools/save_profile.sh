@@ -18,7 +18,7 @@ for kind,sub in (("FETCH_SIZE","pmc_fetch"),("WRITE_SIZE","pmc_write")):
 json.dump(out, open(sys.argv[2],"w"), indent=1, sort_keys=True)
 PY
 }
-for sfx in 1:"" p3:phi3_; do
+for sfx in 1:"" p3:phi3_ f32:fp32_; do
   d=${T}${sfx%%:*}; q=${P}_${sfx##*:}
   [ -d $d/stats ] || continue
   cp $d/stats/*/*_kernel_stats.csv ${q}bench_inflight1_kernel_stats.csv
@@ -31,6 +31,8 @@ done
 for n in phi3 b64 b32 fp8_b32 2rank_gloo; do [ -s $T/bench_$n.json ] && grep '^{' $T/bench_$n.json > ${P}_bench_${n}_line.json; done
 [ -f $T/conc.txt ] && grep -v amdgpu.ids $T/conc.txt > ${P}_concurrent_cost_per_launch.txt
 [ -f $T/conc_phi3.txt ] && grep -v amdgpu.ids $T/conc_phi3.txt > ${P}_phi3_concurrent_cost_per_launch.txt
+[ -f $T/conc_fp32.txt ] && grep -v amdgpu.ids $T/conc_fp32.txt > ${P}_fp32_concurrent_cost_per_launch.txt
+for n in fp32 bf16 phi3; do [ -f $T/plan_$n.txt ] && grep -v amdgpu.ids $T/plan_$n.txt > ${P}_plan_per_launch_$n.txt; done
 [ -f ${T}1/mfma_util.json ] && cp ${T}1/mfma_util.json ${P}_mfma_util.json
 [ -f $T/pytest.log ] && tail -3 $T/pytest.log > ${P}_pytest_gpu_tail.txt
 [ -f $T/pytest_fp8_tail.txt ] && cp $T/pytest_fp8_tail.txt ${P}_pytest_gpu_fp8_build_tail.txt
