@@ -139,3 +139,39 @@ def loss_cases():
             hand=(gt_hand[..., :63] + rng.standard_normal((B, N, 63)) * 0.1).astype(np.float32),
             model_points=(rng.standard_normal((K, P, 3)) * np.array([40, 25, 60])).astype(np.float32))
     return out
+
+
+def rebuilt_real_onnx_export():
+    """tests/golden/onnx_eval_phi0.structure.gz (the reference model as torch.onnx.export wrote it, eval mode, opset 9, payloads blanked:
+    tests/golden/make_golden_onnx.py) with its tensor payloads rebuilt from ``seeded_state_dict(0, 0)``: tensors that kept their names
+    verbatim, BatchNorm-folded convolutions through the numpy restatement of the fold (2.4e-7 from the real payloads).
+    Returns (file bytes, meta dict, {initialiser name: array written})."""
+    import gzip
+    import json
+    import os
+    from hmd_ego_pose_amd import seeded_state_dict
+    from hmd_ego_pose_amd.arch import BN_EPS
+    from hmd_ego_pose_amd.onnx_init import conv_exec_order, initializer_spans, read_nodes
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    meta = json.load(open(os.path.join(gdir, "onnx_eval_phi0.json")))
+    blob = bytearray(gzip.decompress(open(os.path.join(gdir, "onnx_eval_phi0.structure.gz"), "rb").read()))
+    sd = seeded_state_dict(meta["phi"], 0)
+    convs = [n for n in read_nodes(bytes(blob)) if n[0] == "Conv"]
+    want = {}
+    for (_op, ins, _o, _n), (wk, bk, bn) in zip(convs, conv_exec_order(meta["phi"])):
+        if ins[1] in sd:
+            continue
+        g, b, m, v = (sd[bn + k].numpy() for k in (".weight", ".bias", ".running_mean", ".running_var"))
+        sc = (g / np.sqrt(v + np.float32(BN_EPS))).astype(np.float32)
+        want[ins[1]] = (sd[wk].numpy() * sc[:, None, None, None]).astype(np.float32)
+        want[ins[2]] = (((sd[bk].numpy() if bk else np.zeros_like(m)) - m) * sc + b).astype(np.float32)
+    written = {}
+    for name, lo, hi in initializer_spans(bytes(blob)):
+        if name not in meta["tensors"]:
+            continue
+        a = sd[name].numpy() if name in sd else want[name]
+        raw = np.ascontiguousarray(a, "<f4").tobytes()
+        assert len(raw) == hi - lo, name
+        blob[lo:hi] = raw
+        written[name] = a
+    return bytes(blob), meta, written

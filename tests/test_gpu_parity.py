@@ -1009,10 +1009,31 @@ def test_losses_many_object_anchors_and_large_models():
         losses(c(gt_c), c(cls), c(gt_r), c(reg), c(gt_t), c(tra), None, None, np.zeros((1, 2049, 3), np.float32), 3)
 
 
+def test_exported_onnx_model_runs_through_the_c_abi(api, tmp_path):
+    """The reference's deployment artefact - model.onnx as export_to_onnx writes it (hmdegopose/misc_utils.py:36-95: eval mode,
+    BatchNorm folded) - through this build's path: tools/pack_weights.py's reader maps it back to a state_dict, the HEPW pack
+    goes into hep_create, and the HIP fp32 forward must match the oracle run on the ORIGINAL weights within the 1e-3 bound.
+    The .onnx file is the real exporter's structure with its payloads rebuilt from the seeded weights (tests/_util.py)."""
+    from hmd_ego_pose_amd.onnx_init import state_dict_from_onnx
+    from tests._util import rebuilt_real_onnx_export
+    blob, meta, _ = rebuilt_real_onnx_export()
+    path = tmp_path / "model.onnx"; path.write_bytes(blob)
+    rec = state_dict_from_onnx(str(path), 0)
+    sd = api["sd"](0, 0)
+    x = torch.from_numpy(seeded_input((2, 3, 256, 256), 41))
+    ref = api["R"].forward(sd, x, 0)
+    s = api["Session"](rec, 0, 256, 2, "fp32")
+    out = s.forward(x.cuda())
+    torch.cuda.synchronize()
+    for name, a, b in zip(("regression", "classification", "rotation", "translation_raw", "hand"), out[1:], ref[1:]):
+        assert (a.cpu() - b).abs().max().item() <= 1e-3, name
+    s.close()
+
+
 def test_reference_checkpoint_known_answers(api):
     """AUTO-ENABLING known-answer test for the authors' trained phi-0 checkpoint (absent from the reference checkout:
     .MISSING_LARGE_BLOBS lists pytorch-sandbox/onnx-models/model.onnx and the .pth).  Supply it with
-        HEP_REF_WEIGHTS=/path/to/checkpoint.pth   (or a training-mode .onnx export)
+        HEP_REF_WEIGHTS=/path/to/checkpoint.pth   (or the exported model.onnx: eval-mode exports with folded BatchNorm are mapped back)
     and the sample frame tests/golden/000000.png (the reference's onnx-models/000000.png, a data fixture) is pushed through
     preprocess -> forward -> decode -> filter; expected values are the ones the reference documents:
       raw heads at anchor 0   scratchpad.py:78-87   regression [4.3404813, 6.3829317, 0.5551747, -15.24141], classification
@@ -1024,7 +1045,7 @@ def test_reference_checkpoint_known_answers(api):
     import os
     path = os.environ.get("HEP_REF_WEIGHTS", "")
     if not path or not os.path.exists(path):
-        pytest.skip("set HEP_REF_WEIGHTS to the authors' phi-0 checkpoint (.pth, or a training-mode .onnx export)")
+        pytest.skip("set HEP_REF_WEIGHTS to the authors' phi-0 checkpoint (.pth, or the exported .onnx)")
     import math
     from PIL import Image
     from hmd_ego_pose_amd.weights import strip_checkpoint_prefix

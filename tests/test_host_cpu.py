@@ -266,10 +266,11 @@ def _onnx_model(tensors):
 
 
 def test_onnx_initializer_reader_roundtrip_and_pack(tmp_path):
-    """hmd_ego_pose_amd/onnx_init.py against files written here from the published onnx.proto layout (PARITY UNPINNED: no
-    real exporter output exists in this build): raw_data / float_data / int64_data encodings, packed and unpacked dims,
-    negative int64, a scalar; then a whole phi-0 state_dict with `model.` prefixes through tools/pack_weights.py's path,
-    and the refusal of a file whose initialisers are anonymous (eval-mode export with BatchNorm folded)."""
+    """hmd_ego_pose_amd/onnx_init.py against files written here from the published onnx.proto layout (the encodings a real
+    exporter does not happen to use; the real export is test_onnx_reader_against_the_real_eval_mode_export below): raw_data /
+    float_data / int64_data encodings, packed and unpacked dims, negative int64, a scalar; then a whole phi-0 state_dict with
+    `model.` prefixes through tools/pack_weights.py's path, and the refusal of a file whose initialisers are anonymous AND
+    whose graph is not the trace of the architecture (no Conv nodes to map them back by)."""
     import torch
     from hmd_ego_pose_amd import param_spec, seeded_state_dict
     from hmd_ego_pose_amd.onnx_init import read_initializers, state_dict_from_onnx
@@ -297,5 +298,62 @@ def test_onnx_initializer_reader_roundtrip_and_pack(tmp_path):
     a, b = load_pack(pack_bytes(state)), load_pack(pack_bytes(sd))
     assert a.keys() == b.keys() and all(np.array_equal(a[k], b[k]) for k in a)
     anon = _onnx_model([(f"onnx::Conv_{i}", v.numpy(), "raw") for i, (k, v) in enumerate(sd.items()) if v.dtype == torch.float32])
-    with pytest.raises(ValueError, match="anonymous"):
+    with pytest.raises(ValueError, match="Conv nodes"):
         state_dict_from_onnx(anon, 0)
+
+
+def test_onnx_reader_against_the_real_eval_mode_export():
+    """The ONNX reader pinned to a REAL exporter output.  tests/golden/onnx_eval_phi0.structure.gz is what torch.onnx.export wrote for
+    the reference's HMDEgoPose (eval mode, opset 9, exactly as the reference's export_to_onnx: BatchNorm folded into 153
+    anonymous convolutions), every byte of it except the tensor payloads (tests/golden/make_golden_onnx.py).  The payloads are
+    rebuilt here from the seeded weights - the tensors that kept their names bit for bit (sha256 recorded from the real file),
+    the folded ones with the numpy restatement of the fold that the generating script measured at 2.4e-7 from the real
+    payloads - and the file is read back: state_dict_from_onnx maps the anonymous initialisers through the order of the 344
+    Conv nodes, splits the head towers' per-level folds into one shared weight + five scales, and the recovered state_dict must
+    drive the oracle to the same outputs as the original one."""
+    import torch
+    from hmd_ego_pose_amd import seeded_state_dict
+    from hmd_ego_pose_amd.onnx_init import conv_exec_order, read_nodes, state_dict_from_onnx
+    from oracle import efficientpose_ref as R
+    from tests._util import rebuilt_real_onnx_export
+    blob, meta, written = rebuilt_real_onnx_export()
+    assert len(blob) == meta["file_bytes"]
+    phi = meta["phi"]
+    sd = seeded_state_dict(phi, 0)
+    convs = [n for n in read_nodes(blob) if n[0] == "Conv"]
+    seq = conv_exec_order(phi)
+    assert len(convs) == len(seq) == meta["conv_nodes"] == 344
+    for (_op, ins, _o, _n), (wk, _bk, _bn) in zip(convs, seq):
+        assert ins[1] not in sd or ins[1] == wk                   # a convolution that kept its name sits where the trace order says
+    want = {k: v for k, v in written.items() if k not in sd}
+    assert len(want) == meta["folded_initializers"] == 306 and len(written) == len(meta["tensors"]) >= 440
+    for name, a in written.items():
+        e = meta["tensors"][name]
+        assert list(a.shape) == e["shape"], name
+        if "sha256" in e:                                         # the exporter stored the state_dict tensor verbatim
+            assert hashlib.sha256(np.ascontiguousarray(a, "<f4").tobytes()).hexdigest() == e["sha256"], name
+        else:                                                     # folded: float64 sums of the REAL payload
+            assert abs(float(a.astype(np.float64).sum()) - e["sum"]) <= 1e-6 * max(1.0, e["abssum"]), name
+    assert meta["max_abs_diff_real_fold_vs_numpy_fold"] <= 1e-6 and max(meta["max_abs_diff_recovered_state_dict_forward_vs_reference"]) <= 1e-5
+    rec = state_dict_from_onnx(blob, phi)
+    assert list(rec) == list(sd)
+    # tensors that were never folded come back bit for bit; a folded conv comes back as (folded weight, identity BatchNorm + folded bias)
+    for k in ("backbone_net.model._blocks.7._se_reduce.conv.weight", "bifpn.1.p4_w2", "bifpn.2.conv4_up.depthwise_conv.conv.weight", "hand_net.initial_hand_coords.pointwise_conv.conv.bias"):
+        assert torch.equal(rec[k], sd[k]), k
+    p = "backbone_net.model._blocks.3"
+    assert np.array_equal(rec[p + "._project_conv.conv.weight"].numpy(), want[convs[[q[0] for q in seq].index(p + "._project_conv.conv.weight")][1][1]])
+    assert float(rec[p + "._bn2.running_var"].min()) == 1.0 and float(rec[p + "._bn2.running_mean"].abs().max()) == 0.0
+    x = torch.from_numpy(np.random.Generator(np.random.PCG64(3)).standard_normal((1, 3, 128, 128)).astype(np.float32))
+    a, b = R.forward(sd, x, phi), R.forward(rec, x, phi)
+    for u, v in zip(a[1:], b[1:]):
+        assert float((u - v).abs().max()) <= 2e-4 * max(1.0, float(u.abs().max()))
+    # a graph that is not the trace of this architecture is refused: one Conv node fewer
+    data = bytes(blob)
+    from hmd_ego_pose_amd.onnx_init import _fields_at
+    g0 = [(s0, e0) for f, wt, s0, e0 in _fields_at(data, 0, len(data)) if f == 7 and wt == 2][0]
+    with pytest.raises(ValueError, match="Conv nodes|trace order|shape"):
+        nodes = [(s1, e1) for f1, wt1, s1, e1 in _fields_at(data, g0[0], g0[1]) if f1 == 1 and wt1 == 2]
+        lo, hi = nodes[[i for i, (s1, e1) in enumerate(nodes) if b'"\x04Conv' in data[s1:e1]][40]]      # (op_type field: tag 0x22, length 4)
+        cut = bytearray(data)
+        cut[lo:hi] = data[lo:hi].replace(b'"\x04Conv', b'"\x04Conx')          # (same length: the enclosing length prefixes stay valid)
+        state_dict_from_onnx(bytes(cut), phi)

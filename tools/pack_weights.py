@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Convert a reference checkpoint (.pth state_dict, keys un-prefixed, `model.` or `model.module.`
-prefixed - pytorch-sandbox/evaluate.py:102-116) or an exported .onnx whose initialisers carry the state_dict
-names (hmd_ego_pose_amd/onnx_init.py) into the HEPW weight pack that libhep.so reads.
+prefixed - pytorch-sandbox/evaluate.py:102-116) or an exported .onnx - a training-mode export whose initialisers carry the state_dict
+names, or the eval-mode export of the reference's export_to_onnx with BatchNorm folded (hmd_ego_pose_amd/onnx_init.py) into the HEPW weight pack that libhep.so reads.
 
     python tools/pack_weights.py weights/syn_colibri/fold_0/phi_0_....pth model.hepw --phi 0
 """
