@@ -109,6 +109,9 @@ template <bool BF16, int CW, bool HDR> struct TowerCfg {
   static constexpr size_t XA_BYTES = (size_t)NW * KS * 64 * 16;
   static constexpr bool WLDS = (size_t)WROWS * WP * ES <= (BF16 ? TOWER_WLDS_MAX : 48 * 1024) && (size_t)WROWS * WP * ES + (size_t)9 * CW * 4 + WROWS * 4 + XA_BYTES <= 158 * 1024;
   static constexpr int HP = CW + 16 / ES;                             // halo pixel pitch (elements): +16 bytes
+  // (round 4, fp32 at width 64: without the halos - 36 KB of LDS, four workgroups per CU instead of two - a tower layer takes 42 us
+  //  against 31 us and the headers 96 against 66: the halo's coalesced loads are worth more than the occupancy; three waves per
+  //  SIMD in the launch bounds with the halos: 29.3 against 30.9 us, inside the noise of the step)
   static constexpr bool HALO = (size_t)4 * 36 * HP * ES <= 40 * 1024;  // the 6x6-pixel halos of 4 waves fit
   static constexpr int BIAS = WROWS;                                  // bias floats staged per segment (one per weight row)
   static constexpr size_t OFF_XA = ((size_t)9 * CW + BIAS) * 4;
