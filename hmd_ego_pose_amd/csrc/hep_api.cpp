@@ -725,7 +725,7 @@ int hep_kernel_symbol(const hep_handle* h, int i, const char** symbol) try {
     case OP_DW: snprintf(tmp, sizeof tmp, "dw_kernel<%s, %d, %d, %d>", t, o.dw.k, o.dw.s, o.dw.TW); break;
     case OP_POOL: snprintf(tmp, sizeof tmp, "pool_kernel<%s>", t); break;
     case OP_PWG: snprintf(tmp, sizeof tmp, "pw_group_kernel<%s>", t); break;
-    case OP_CHAIN: snprintf(tmp, sizeof tmp, "chain_kernel<%s, %s>", o.chain.bf16 ? "true" : "false", o.chain.stream_w ? "true" : "false"); break;
+    case OP_CHAIN: snprintf(tmp, sizeof tmp, "chain_kernel<%s, %d>", o.chain.bf16 ? "true" : "false", o.chain.stream_w); break;
     case OP_SE: snprintf(tmp, sizeof tmp, "se_finish_kernel<%s>", t); break;
     case OP_MBF: snprintf(tmp, sizeof tmp, "mbf_kernel<%s, %d, %d, %d, %s, %d>", t, o.mbf.k, o.mbf.s, o.mbf.ts, o.mbf.fp8 ? "true" : "false",
                           o.mbf.has_expand && o.mbf.npass > 1 ? (o.mbf.mp_resident ? 2 : 1) : 0);      // (last argument: 1 / 2 = multi-pass expand)

@@ -190,7 +190,7 @@ struct ChainArgs {
   const ChainNode* nodes; const void* wblob;             // device: node table, the nodes' weights in LDS layout
   ChainExt ext[CH_MAX_EXT];
   int nnodes, nconv, next, B, C, wnode_bytes;           // nconv: nodes with a convolution (the others are plain max-pools)
-  int bf16, stream_w;                                    // session dtype; stream_w: LDS holds ONE node's weights, the next node's arrive under the running one
+  int bf16, stream_w;                                    // session dtype; stream_w: 0 all node weights resident in LDS, 1 two nodes' weights in LDS (the next node's streamed by LDS-DMA), 2 pointwise weights straight from global memory
   uint32_t nt_rcp;                                       // rcp_u32(ceil(C / 16)): (m-tile, n-tile) pair -> m-tile (filled by launch_chain)
   size_t off_w, off_halo, off_atile, lds_bytes;
 };

@@ -975,10 +975,16 @@ struct Planner {
     const size_t halo_b = (((size_t)(hw_max + 2) * (hw_max + 2) * (C + pad) * es2 + 15) & ~(size_t)15);
     const size_t atile_b = (size_t)((hw_max * hw_max + 15) & ~15) * (C + pad) * es2;
     ca.off_w = ((size_t)top * es2 + 15) & ~(size_t)15;
-    // all node weights resident when they fit; else two nodes' weights in LDS, the next node's streamed under the running one (fp32)
-    ca.stream_w = (ca.off_w + (size_t)nconv * wnode_bytes + halo_b + atile_b > 158 * 1024) ? 1 : 0;
-    if (const char* e = getenv("HEP_CHAIN_STREAM")) ca.stream_w = atoi(e) != 0;                          // A/B knob, parity test of the streamed form in bf16
-    ca.off_halo = ca.off_w + (size_t)(ca.stream_w ? std::min(2, nconv) : nconv) * wnode_bytes;
+    // all node weights resident when they fit; else two nodes' weights in LDS, the next node's streamed under the running one (fp32
+    // at width 64); else only the depthwise weights + biases in LDS and the pointwise fragments straight from global memory (width 160)
+    const size_t wsmall = (size_t)10 * C * 4;
+    auto wlds = [&](int mode) { return mode == 2 ? (size_t)nconv * wsmall : (size_t)(mode == 1 ? std::min(2, nconv) : nconv) * wnode_bytes; };
+    ca.stream_w = 0;
+    while (ca.stream_w < 2 && ca.off_w + wlds(ca.stream_w) + halo_b + atile_b > 158 * 1024) ca.stream_w++;
+    if (const char* e = getenv("HEP_CHAIN_STREAM")) ca.stream_w = std::max(0, std::min(2, atoi(e)));     // A/B knob, parity tests of the other forms in bf16
+    if (ca.stream_w == 2 && (C + (s->dtype ? 31 : 15)) / (s->dtype ? 32 : 16) > 6) return false;         // six k-steps of fragments in registers
+    if (ca.stream_w == 2 && getenv("HEP_CHAIN_WGLOBAL") && atoi(getenv("HEP_CHAIN_WGLOBAL")) == 0) return false;
+    ca.off_halo = ca.off_w + wlds(ca.stream_w);
     ca.off_atile = ca.off_halo + halo_b;
     ca.lds_bytes = ca.off_atile + atile_b;
     if (ca.lds_bytes > 158 * 1024) return false;

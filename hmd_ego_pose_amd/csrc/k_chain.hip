@@ -113,8 +113,13 @@ template <bool BF16, typename T> __device__ __forceinline__ void slot_pool(const
 
 }  // namespace
 
-template <bool BF16, bool STREAM>
+// WMODE: where a node's weights live.  0: all nodes' weights resident in LDS (bf16, width 64); 1: two nodes' weights in LDS, the next
+// node's streamed in by LDS-DMA under the running node (fp32, width 64); 2: only the depthwise weights and biases in LDS, the pointwise
+// weight fragments of an (m-tile, n-tile) pair requested together straight from global memory (L2) in front of its MFMAs (width 160:
+// one node's pointwise weights are 60 KB and do not fit next to three 8x8x160 maps).
+template <bool BF16, int WMODE>
 __global__ __launch_bounds__(CHAIN_THREADS) void chain_kernel(ChainArgs a) {
+  constexpr bool STREAM = WMODE == 1, WGLOBAL = WMODE == 2;
   typedef Vec8<BF16> V;
   typedef typename V::elem T;
   typedef Raw8<BF16> R8;
@@ -142,10 +147,16 @@ __global__ __launch_bounds__(CHAIN_THREADS) void chain_kernel(ChainArgs a) {
     // the chain's weights: one contiguous blob already in the LDS layout (per node [9*C] f32 depthwise | [C] f32 bias |
     // [C][C+PAD] bf16 pointwise rows)
     constexpr int WB = 4096 / CHAIN_THREADS;
-    const int wvecs = (int)(((size_t)(STREAM ? 1 : a.nconv) * a.wnode_bytes) >> 4);
+    // (WGLOBAL: the first 10 * C floats of every node - depthwise weights and bias - packed node after node)
+    const int svecs = (10 * C * 4) >> 4;
+    const int wvecs = WGLOBAL ? a.nconv * svecs : (int)(((size_t)(STREAM ? 1 : a.nconv) * a.wnode_bytes) >> 4);
+    auto wsrc_of = [&](int i) -> const u32x4* {
+      if constexpr (WGLOBAL) { const int nd_ = i / svecs, o = i - nd_ * svecs; return reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(a.wblob) + (size_t)nd_ * a.wnode_bytes) + o; }
+      else return reinterpret_cast<const u32x4*>(a.wblob) + i;
+    };
     u32x4 wv[WB];
 #pragma unroll
-    for (int j = 0; j < WB; j++) { const int i = tid + j * CHAIN_THREADS; if (i < wvecs) wv[j] = reinterpret_cast<const u32x4*>(a.wblob)[i]; }
+    for (int j = 0; j < WB; j++) { const int i = tid + j * CHAIN_THREADS; if (i < wvecs) wv[j] = *wsrc_of(i); }
     // external maps that are copied as they are (their own resolution)
     constexpr int EPF = BF16 ? CH_MAX_EXT : 4;          // maps whose first row of vectors is prefetched (fp32: 8 registers each)
     R8 ev[EPF];
@@ -158,7 +169,7 @@ __global__ __launch_bounds__(CHAIN_THREADS) void chain_kernel(ChainArgs a) {
     }
 #pragma unroll
     for (int j = 0; j < WB; j++) { const int i = tid + j * CHAIN_THREADS; if (i < wvecs) reinterpret_cast<u32x4*>(wreg)[i] = wv[j]; }
-    for (int i = tid + WB * CHAIN_THREADS; i < wvecs; i += CHAIN_THREADS) reinterpret_cast<u32x4*>(wreg)[i] = reinterpret_cast<const u32x4*>(a.wblob)[i];   // (more nodes / wider maps)
+    for (int i = tid + WB * CHAIN_THREADS; i < wvecs; i += CHAIN_THREADS) reinterpret_cast<u32x4*>(wreg)[i] = *wsrc_of(i);   // (more nodes / wider maps)
 #pragma unroll
     for (int e = 0; e < CH_MAX_EXT; e++) {
       const ChainExt& x = a.ext[e];
@@ -215,9 +226,10 @@ __global__ __launch_bounds__(CHAIN_THREADS) void chain_kernel(ChainArgs a) {
       __syncthreads();
       continue;
     }
-    const float* wdw_s = reinterpret_cast<const float*>(wreg + (size_t)(STREAM ? (nd.widx & 1) : nd.widx) * a.wnode_bytes);
+    const float* wdw_s = reinterpret_cast<const float*>(wreg + (WGLOBAL ? (size_t)nd.widx * (10 * C * 4) : (size_t)(STREAM ? (nd.widx & 1) : nd.widx) * a.wnode_bytes));
     const float* bias_s = wdw_s + 9 * C;
-    const T* wpw_s = reinterpret_cast<const T*>(bias_s + C);
+    const T* wpw_s = reinterpret_cast<const T*>(bias_s + C);                       // (resident / streamed forms)
+    const T* wpw_g = reinterpret_cast<const T*>(reinterpret_cast<const unsigned char*>(a.wblob) + (size_t)nd.widx * a.wnode_bytes + (size_t)10 * C * 4);
     // streamed weights: the NEXT node's go straight from global memory into the other LDS buffer (LDS-DMA, no registers: held in
     // registers under the node they spilled); that buffer was last read by the previous node, which every wave has left
     // (its closing barrier).  1 KB per wave instruction; the host pads a node's weights to whole KB.
@@ -285,9 +297,29 @@ __global__ __launch_bounds__(CHAIN_THREADS) void chain_kernel(ChainArgs a) {
     for (int pair = wave; pair < mt_n * nt_n; pair += CHAIN_WAVES) {
       const int mt = udiv_rcp(pair, a.nt_rcp), nt = pair - mt * nt_n;      // (host-made reciprocal: a 64-bit division sat here)
       const int m = mt * 16 + r;
-      const T* wrow = wpw_s + (int64_t)(nt * 16 + r) * CH + KLANE * g;
+      const T* wrow = (WGLOBAL ? wpw_g : wpw_s) + (int64_t)(nt * 16 + r) * CH + KLANE * g;
       const T* arow = atile + (int64_t)m * CH + KLANE * g;
       f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if constexpr (WGLOBAL) {
+        // every k-step's weight fragment of the pair is requested before the first MFMA (one L2 round trip per pair, not per
+        // k-step); unconditional loads on clamped offsets, k >= C meets a zeroed activation fragment
+        constexpr int KSG = 6;                                                   // C <= 192 (bf16) / 96 (fp32): host-checked
+        frag_t wfr[KSG];
+#pragma unroll
+        for (int ks = 0; ks < KSG; ks++) wfr[ks] = *reinterpret_cast<const frag_t*>(wrow + min(ks * KSTEP, C - KLANE - KLANE * g));
+#pragma unroll
+        for (int ks = 0; ks < KSG; ks++) {
+          if (ks < ksteps) {
+            frag_t xa = {};
+            if (ks * KSTEP + KLANE * g < C) xa = *reinterpret_cast<const frag_t*>(arow + ks * KSTEP);
+            if constexpr (BF16) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wfr[ks]), __builtin_bit_cast(bf16x8, xa), acc, 0, 0, 0);
+            else {
+#pragma unroll
+              for (int q = 0; q < 4; q++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wfr[ks][q], xa[q], acc, 0, 0, 0);
+            }
+          }
+        }
+      } else
       for (int ks = 0; ks < ksteps; ks++) {
         frag_t wf = {}, xa = {};
         if (ks * KSTEP + KLANE * g < C) { wf = *reinterpret_cast<const frag_t*>(wrow + ks * KSTEP); xa = *reinterpret_cast<const frag_t*>(arow + ks * KSTEP); }
@@ -330,19 +362,24 @@ extern "C" int hep_dbg_chain_trace(unsigned long long* host, int nblocks, int en
 }
 #endif
 
-template <bool BF16, bool STREAM> static int chain_prep_one() {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel<BF16, STREAM>), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024) == hipSuccess ? 0 : -1;
+template <bool BF16, int WMODE> static int chain_prep_one() {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel<BF16, WMODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024) == hipSuccess ? 0 : -1;
 }
-int chain_prepare(void) { return chain_prep_one<true, false>() | chain_prep_one<true, true>() | chain_prep_one<false, false>() | chain_prep_one<false, true>(); }
+int chain_prepare(void) {
+  return chain_prep_one<true, 0>() | chain_prep_one<true, 1>() | chain_prep_one<true, 2>() | chain_prep_one<false, 0>() | chain_prep_one<false, 1>() | chain_prep_one<false, 2>();
+}
 
 void launch_chain(const ChainArgs& a_, hipStream_t s) {
   ChainArgs a = a_;
   a.nt_rcp = rcp_u32((uint32_t)((a.C + 15) >> 4));
+  const dim3 g(a.B), b(CHAIN_THREADS);
   if (a.bf16) {
-    if (a.stream_w) hipLaunchKernelGGL((chain_kernel<true, true>), dim3(a.B), dim3(CHAIN_THREADS), a.lds_bytes, s, a);
-    else hipLaunchKernelGGL((chain_kernel<true, false>), dim3(a.B), dim3(CHAIN_THREADS), a.lds_bytes, s, a);
+    if (a.stream_w == 2) hipLaunchKernelGGL((chain_kernel<true, 2>), g, b, a.lds_bytes, s, a);
+    else if (a.stream_w == 1) hipLaunchKernelGGL((chain_kernel<true, 1>), g, b, a.lds_bytes, s, a);
+    else hipLaunchKernelGGL((chain_kernel<true, 0>), g, b, a.lds_bytes, s, a);
   } else {
-    if (a.stream_w) hipLaunchKernelGGL((chain_kernel<false, true>), dim3(a.B), dim3(CHAIN_THREADS), a.lds_bytes, s, a);
-    else hipLaunchKernelGGL((chain_kernel<false, false>), dim3(a.B), dim3(CHAIN_THREADS), a.lds_bytes, s, a);
+    if (a.stream_w == 2) hipLaunchKernelGGL((chain_kernel<false, 2>), g, b, a.lds_bytes, s, a);
+    else if (a.stream_w == 1) hipLaunchKernelGGL((chain_kernel<false, 1>), g, b, a.lds_bytes, s, a);
+    else hipLaunchKernelGGL((chain_kernel<false, 0>), g, b, a.lds_bytes, s, a);
   }
 }

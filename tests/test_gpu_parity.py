@@ -518,19 +518,19 @@ def test_default_fp32_plan_uses_multi_pass_fronts(api):
 
 
 def test_default_fp32_plan_runs_its_chains_in_lds(api):
-    """fp32 sessions at BiFPN width 64 run the small-level node chains on chain_kernel<false, true> (weights streamed by LDS-DMA),
+    """fp32 sessions at BiFPN width 64 run the small-level node chains on chain_kernel<false, 1> (weights streamed by LDS-DMA),
     not on the k_sep.hip fallback."""
     s = api["Session"](api["sd"](0, 4), 0, 256, 2, "fp32")
     syms = [y for _, y in _plan_syms(s, 2)]
     s.close()
-    assert sum(y.startswith("chain_kernel<false") for y in syms) == 4 and "chain_kernel<false, true>" in syms and not any("sep_kernel<false, 2" in y for y in syms), syms
+    assert sum(y.startswith("chain_kernel<false") for y in syms) == 4 and "chain_kernel<false, 1>" in syms and not any("sep_kernel<false, 2" in y for y in syms), syms
 
 
-@pytest.mark.parametrize("phi,env", [(1, {"HEP_SEP_WLDS": "0"}), (3, {"HEP_SEP_WLDS": "0"}), (0, {"HEP_CHAIN_STREAM": "1"})])
+@pytest.mark.parametrize("phi,env", [(1, {"HEP_SEP_WLDS": "0"}), (3, {"HEP_SEP_WLDS": "0"}), (0, {"HEP_CHAIN_STREAM": "1"}), (0, {"HEP_CHAIN_STREAM": "2"}), (3, {"HEP_CHAIN_WGLOBAL": "0"})])
 def test_bf16_plan_variants_are_bit_identical(api, phi, env, monkeypatch):
     """A plan choice that only moves data differently - BiFPN nodes wider than 64 channels with their pointwise weights staged
-    in LDS or fetched per fragment (widths 88 and 160), LDS-resident node chains with all node weights resident or streamed by
-    LDS-DMA (width 64) - leaves the arithmetic and its order alone: bf16 sessions must agree bit for bit."""
+    in LDS or fetched per fragment (widths 88 and 160), LDS-resident node chains with all node weights resident, streamed by
+    LDS-DMA or with their pointwise fragments straight from global memory (width 64; width 160 against the k_sep.hip chains) - leaves the arithmetic and its order alone: bf16 sessions must agree bit for bit."""
     size, batch = 256, 2
     sd = api["sd"](phi, 5)
     x = torch.from_numpy(seeded_input((batch, 3, size, size), 23)).cuda()
