@@ -574,7 +574,7 @@ struct Planner {
         for (int ts_ : {16, 8}) {
           if (ts_ == 16 && !ts16_ok) continue;
           const int mi = mbf_max_inside(Hin, Win, b.k, b.stride, pt, pl, ts_);
-          for (int cc_ : {64, 32})
+          for (int cc_ : {64, 48, 32})                        // (48: three n-tiles - fewer passes where the 64-wide expanded tile leaves no room for a wider K slice)
             for (int kpp = 3; kpp >= 1; kpp--) {              // k-steps per pass
               const int kp_ = kpp * kstep, np_ = (b.cin + kp_ - 1) / kp_;
               if (np_ < 2 || kpp > ksteps || !mbf_mp_fits(cc_, kp_, s->dtype, mi, ts_)) continue;
@@ -587,6 +587,7 @@ struct Planner {
             }
         }
         if (best.npass > 1) { ts = best.ts; CC = best.CC; npass = best.npass; kp = best.kp; max_in = mbf_max_inside(Hin, Win, b.k, b.stride, pt, pl, ts); }
+        if (getenv("HEP_PLAN_DEBUG")) fprintf(stderr, "libhep plan: block %d front: tile %d, %d channels per workgroup, %d pass(es) of %d input channels, %ld round(s)\n", i, ts, CC, npass, kp ? kp : b.cin, best.rounds);
       }
     }
     // squeeze-excite weights: reduce FC [sq][Cexp] (fp32) for the front kernel; bias, expand FC [Cexp][sqp] (session
