@@ -145,7 +145,7 @@ def describe(local_rank: int) -> str:
     """One line per rank for the job log, printed BEFORE the first collective: rank / world, backend, RCCL (nccl) version as
     torch reports it and the device this rank drives - the first thing to read when an N-GPU run misbehaves."""
     rank, world = (dist.get_rank(), dist.get_world_size()) if (dist.is_available() and dist.is_initialized()) else (0, 1)
-    be = dist.get_backend() if world > 1 else "none"
+    be = dist.get_backend() if (dist.is_available() and dist.is_initialized()) else "none"
     ver = "n/a"
     try:
         if torch.cuda.is_available():

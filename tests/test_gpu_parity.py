@@ -1112,6 +1112,32 @@ def test_bench_line_contract():
     assert "not the parity-tested weight set" in d["comm"]["what"]
 
 
+def test_rccl_initialises_and_reduces_on_this_box():
+    """The one thing about RCCL a single-GPU box can show: the library torch's "nccl" backend binds to loads, creates a communicator on
+    the MI355X, and runs a collective and a barrier (world size 1 - RCCL refuses two ranks on one device, so the point-to-point scatter /
+    gather of hmd_ego_pose_amd/dist.py stays covered by the gloo tests and the skipped 2-GPU test below).  Runs in a fresh child process;
+    prints the per-rank line bench.py logs before its first collective (backend, RCCL version, device)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import os, sys, datetime, torch, torch.distributed as dist\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "from hmd_ego_pose_amd import dist as hd\n"
+        "torch.cuda.set_device(0)\n"
+        "dist.init_process_group('nccl', rank=0, world_size=1, timeout=datetime.timedelta(seconds=120))\n"
+        "print(hd.describe(0))\n"
+        "t = torch.arange(8, dtype=torch.float32, device='cuda')\n"
+        "dist.all_reduce(t); dist.broadcast(t, 0); dist.barrier(); torch.cuda.synchronize()\n"
+        "assert t.tolist() == list(range(8)), t\n"
+        "assert hd.max_over_ranks(1.5, torch.device('cuda', 0)) == 1.5\n"
+        "dist.destroy_process_group(); print('rccl ok')\n")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29631", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "rccl ok" in r.stdout and "backend nccl" in r.stdout, (r.stdout[-600:], r.stderr[-1200:])
+    print(r.stdout.strip().splitlines()[0])
+
+
 def test_two_gpu_rccl_bench_line():
     """bench.py --gpus 2 on a box with two or more MI355X: the script starts its own rank processes, the weights are
     broadcast and the frames scattered / detections gathered over RCCL (backend nccl), rank 0 prints one JSON line.
