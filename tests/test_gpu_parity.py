@@ -1130,6 +1130,9 @@ def test_rccl_initialises_and_reduces_on_this_box():
         "dist.all_reduce(t); dist.broadcast(t, 0); dist.barrier(); torch.cuda.synchronize()\n"
         "assert t.tolist() == list(range(8)), t\n"
         "assert hd.max_over_ranks(1.5, torch.device('cuda', 0)) == 1.5\n"
+        "a = torch.arange(1 << 16, dtype=torch.uint8, device='cuda'); b = torch.zeros_like(a)\n"          # the grouped point-to-point form of scatter_frames / gather_detections, rank 0 to itself
+        "for q in dist.batch_isend_irecv([dist.P2POp(dist.isend, a, 0), dist.P2POp(dist.irecv, b, 0)]): q.wait()\n"
+        "torch.cuda.synchronize(); assert torch.equal(a, b)\n"
         "dist.destroy_process_group(); print('rccl ok')\n")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29631", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
                HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
