@@ -1112,6 +1112,18 @@ def test_bench_line_contract():
     assert "not the parity-tested weight set" in d["comm"]["what"]
 
 
+@pytest.mark.parametrize("precision,env", [("fp32", {}), ("bf16", {"HEP_CHAIN_STREAM": "1"})])
+def test_results_are_bit_reproducible_with_four_batches_in_flight(precision, env):
+    """tools/soak.py: four sessions in flight on four streams, the same frames every step, every sampled result bit-identical to the
+    first one.  Load-dependent races - a missing wait behind the LDS-DMA weight stream of chain_kernel (fp32 sessions; forced for bf16
+    here), a scratch buffer shared across streams - do not show with one batch in flight."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak.py"), precision, "0", "256", "16", "600"], env=dict(os.environ, **env),
+                       capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0 and "0 mismatching snapshots" in r.stdout, (r.stdout[-800:], r.stderr[-800:])
+
+
 def test_rccl_initialises_and_reduces_on_this_box():
     """The one thing about RCCL a single-GPU box can show: the library torch's "nccl" backend binds to loads, creates a communicator on
     the MI355X, and runs a collective and a barrier (world size 1 - RCCL refuses two ranks on one device, so the point-to-point scatter /
