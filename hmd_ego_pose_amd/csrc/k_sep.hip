@@ -192,10 +192,18 @@ __global__ __launch_bounds__(SEP_THREADS_OF(MODE, BF16), MODE == 1 ? SEP_M1_WAVE
   };
 
   // ---- phase 1: fused (+swish) halo of the depthwise input, zero outside the image ----
+  // (thread -> (position, channel group): an exact split by CG through a float reciprocal - with the power-of-two split a 160-channel
+  //  node used 20 of every 32 lanes: four sweeps over its 100 halo positions instead of two)
+  //  (single nodes only: in the multi-segment and chain instantiations the extra live values spilled)
+  constexpr bool EXACT = MODE == 0;
+  const float cg_rinv = __builtin_amdgcn_rcpf((float)CG);
+  const int t_pos = EXACT ? udiv_f((int)threadIdx.x, CG, cg_rinv) : (int)(threadIdx.x >> cgsh);
+  const int t_cg = EXACT ? (int)threadIdx.x - t_pos * CG : (int)(threadIdx.x & ((1 << cgsh) - 1));
+  const int t_stride = EXACT ? udiv_f(SEP_THREADS, CG, cg_rinv) : (SEP_THREADS >> cgsh);
   {
-    const int cg = threadIdx.x & ((1 << cgsh) - 1);
+    const int cg = t_pos < t_stride ? t_cg : CG;                      // (the last SEP_THREADS % CG threads idle)
     if (cg < CG)
-      for (int pos = threadIdx.x >> cgsh; pos < HS * HS; pos += SEP_THREADS >> cgsh) {
+      for (int pos = t_pos; pos < HS * HS; pos += t_stride) {
         const int hy = TS == 16 ? pos / 18 : (TS == 8 ? pos / 10 : pos / 6), hx = pos - hy * HS;
         const int y = y0 + hy - 1, x = x0 + hx - 1;
         float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -218,9 +226,9 @@ __global__ __launch_bounds__(SEP_THREADS_OF(MODE, BF16), MODE == 1 ? SEP_M1_WAVE
 
   // ---- phase 2: depthwise 3x3 -> operand tile [TS*TS pixels][C] ----
   {
-    const int cg = threadIdx.x & ((1 << cgsh) - 1);
+    const int cg = t_pos < t_stride ? t_cg : CG;
     if (cg < CG)
-      for (int p = threadIdx.x >> cgsh; p < TS * TS; p += SEP_THREADS >> cgsh) {
+      for (int p = t_pos; p < TS * TS; p += t_stride) {
         const int py = p >> tssh, px = p & (TS - 1);
         float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
