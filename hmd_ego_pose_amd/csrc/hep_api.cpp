@@ -733,7 +733,7 @@ int hep_kernel_symbol(const hep_handle* h, int i, const char** symbol) try {
     case OP_SBF: snprintf(tmp, sizeof tmp, "sbf_kernel<%s>", t); break;
     case OP_XBF: { const int sp = xbf_specialised(o.xbf);
                    snprintf(tmp, sizeof tmp, "xbf_kernel<%s, %d, %d, %d, %d, %d, %d, %d>", t, o.xbf.k, o.xbf.s, o.xbf.toh, o.xbf.tow, o.xbf.NT1, sp ? o.xbf.K1 : 0, sp ? o.xbf.NT2 : 0); break; }
-    default: if (o.sep.direct) snprintf(tmp, sizeof tmp, "tower_kernel<%s, %d, %s>", t, o.sep.C, o.sep.direct == 2 ? "true" : "false");
+    default: if (o.sep.direct) snprintf(tmp, sizeof tmp, "%s<%s, %d, %s>", o.sep.coop ? "tower_coop_kernel" : "tower_kernel", t, o.sep.C, o.sep.direct == 2 ? "true" : "false");
              else {
                const int mode = o.sep.chain ? 2 : (o.sep.nseg == 1 ? 0 : 1);
                const bool wl = o.sep.bf16 && o.sep.off_wpw && mode != 1;         // (launch_sep: staged pointwise weights)

@@ -169,6 +169,7 @@ struct SepArgs {
   int nseg; int B; int total_tiles; int bf16; int C;
   int chain;                                 // segments are a dependency chain run by one workgroup per image
   int direct;                                // k_tower.hip (wave-per-patch, no LDS staging): 1 = map layer, 2 = headers
+  int coop;                                  // ... in its cooperative form (tower_coop_kernel: one 10x10 halo per workgroup, weights in registers)
   size_t off_atile, off_wdw, off_bias, lds_bytes;   // LDS layout (k_sep.hip: sep_lds_layout)
   size_t off_wpw;                            // 0, or where the node's pointwise weights [C][C + pad] are staged (bf16 nodes wider than 64 that fit)
 };
@@ -293,6 +294,7 @@ constexpr int tower_hdr_tiles(int C, bool bf16) {
   return t < 1 ? 1 : (t > 12 ? 12 : (int)t);
 }
 int tower_prepare(void);         // raises the dynamic-LDS limit of the tower kernels (call once per device)
+int tower_coop_supported(int C, int bf16);   // widths / dtypes tower_coop_kernel is instantiated for
 int tower_supports(int C);       // BiFPN widths k_tower.hip is instantiated for
 int tower_map_tiles(int C);      // n-tiles (even) of a map layer: its weight rows are permuted, see k_tower.hip
 void launch_decode(const DecodeArgs&, hipStream_t);

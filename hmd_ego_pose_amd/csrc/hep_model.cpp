@@ -835,6 +835,13 @@ struct Planner {
     o.sep.nseg = (int)o.segs.size(); o.sep.total_tiles = tile_begin; o.sep.bf16 = s->dtype; o.sep.C = C;
     o.sep.chain = chain && o.segs.size() > 1;
     o.sep.direct = direct;
+    // cooperative tower form wherever it is instantiated: bf16 from width 160, where the wave-private halos of tower_kernel no
+    // longer fit (phi 3 @ 512 b8: 5.02k -> 5.14k frames/s), and fp32 at width 64 (24.7k -> 25.7k); HEP_TOWER_COOP=0 turns it off
+    o.sep.coop = 0;
+    if (direct && tower_coop_supported(C, s->dtype != 0)) {
+      const char* e = getenv("HEP_TOWER_COOP");
+      o.sep.coop = e ? (atoi(e) != 0) : 1;
+    }
     bool all_maps = true;
     for (const SegSpec& sp : specs) all_maps = all_maps && sp.out_t >= 0 && sp.N == C;
     sep_lds_layout(C, s->dtype, ts_max, cols_f32, cols_map, &o.sep, (chain || specs.size() == 1) && all_maps && !direct && !(getenv("HEP_SEP_WLDS") && atoi(getenv("HEP_SEP_WLDS")) == 0));

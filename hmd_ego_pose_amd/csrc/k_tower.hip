@@ -66,6 +66,14 @@ template <> struct Frag<true> {
     c.a[2] = __builtin_elementwise_fma(e1, (f32x2){wb[0], wb[1]}, c.a[2]);
     c.a[3] = __builtin_elementwise_fma(o1, (f32x2){wb[2], wb[3]}, c.a[3]);
   }
+  static __device__ __forceinline__ void fma_tap_r(Acc& c, const raw& x, const f32x4& wa, const f32x4& wb) {   // weights in registers (swizzled)
+    const f32x2 e0 = {__uint_as_float(x[0] << 16), __uint_as_float(x[1] << 16)}, o0 = {__uint_as_float(x[0] & 0xffff0000u), __uint_as_float(x[1] & 0xffff0000u)};
+    const f32x2 e1 = {__uint_as_float(x[2] << 16), __uint_as_float(x[3] << 16)}, o1 = {__uint_as_float(x[2] & 0xffff0000u), __uint_as_float(x[3] & 0xffff0000u)};
+    c.a[0] = __builtin_elementwise_fma(e0, (f32x2){wa[0], wa[1]}, c.a[0]);
+    c.a[1] = __builtin_elementwise_fma(o0, (f32x2){wa[2], wa[3]}, c.a[1]);
+    c.a[2] = __builtin_elementwise_fma(e1, (f32x2){wb[0], wb[1]}, c.a[2]);
+    c.a[3] = __builtin_elementwise_fma(o1, (f32x2){wb[2], wb[3]}, c.a[3]);
+  }
   static __device__ __forceinline__ raw pack(const Acc& c) {
     return (raw){pack_bf16x2(c.a[0][0], c.a[1][0]), pack_bf16x2(c.a[0][1], c.a[1][1]), pack_bf16x2(c.a[2][0], c.a[3][0]), pack_bf16x2(c.a[2][1], c.a[3][1])};
   }
@@ -81,6 +89,7 @@ template <> struct Frag<false> {
   static __device__ __forceinline__ void fma_tap(Acc& c, const raw& x, const float* w) {
     c.a = __builtin_elementwise_fma(x, *reinterpret_cast<const f32x4*>(w), c.a);
   }
+  static __device__ __forceinline__ void fma_tap_r(Acc& c, const raw& x, const f32x4& wa, const f32x4&) { c.a = __builtin_elementwise_fma(x, wa, c.a); }
   static __device__ __forceinline__ raw pack(const Acc& c) { return c.a; }
   static __device__ __forceinline__ f32x4 mma(const raw& a, const raw& b, f32x4 c) {
 #pragma unroll
@@ -389,6 +398,276 @@ __global__ __launch_bounds__(256, BF16 ? 4 : 2) void tower_kernel(const SepSeg* 
 #endif
 }
 
+
+// ---- cooperative form: the layers whose wave-private halos do not fit next to the pointwise weights (bf16 from width 160) ----
+// tower_kernel above keeps a layer's [N][C] pointwise weights in LDS for its four independent waves; at width 160 that is 54 KB,
+// the four 6x6 halos (48 KB) no longer fit and every tap became a direct load in the MFMA lane layout (four cache lines per
+// quad: 1.95 TB/s at phi 3 @ 512, and per wave and image 100 weight-fragment + 90 depthwise-weight LDS reads).  Here the
+// WORKGROUP owns the 8x8 tile and the waves divide the layer between them:
+//   * wave w holds the weight fragments of output unit w (bf16: the n-tile pair 2w, 2w+1 = 8 consecutive channels per lane,
+//     one 16-byte store; fp32: n-tile w) for ALL k-steps in registers (KS x UN x 4 VGPRs) - loaded once per workgroup, reused
+//     for the four m-tiles of every image; headers: units w, w + NWV, ...
+//   * the tile's ONE 10x10 halo arrives by coalesced 16-byte lanes (consecutive lanes = consecutive channels of a pixel) into
+//     LDS; the next image's halo is in flight in registers while this one is worked on,
+//   * depthwise: wave w computes k-step w of all four m-tiles (its 9 x 8 weights in registers) and parks the operand fragments
+//     in LDS in MFMA lane order; after the barrier every wave multiplies its unit against all of them.
+// The widths pair up: k-steps == units for every BiFPN width in bf16 (in fp32 units >= k-steps), so NWV = units.
+// Two barriers per image; LDS at width 160: 33.6 KB halo + 20 KB fragments + bias = 55 KB, two workgroups (10 waves) per CU.
+template <bool BF16, int CW, bool HDR> struct CoopCfg {
+  static constexpr int ES = BF16 ? 2 : 4, KL = BF16 ? 8 : 4, KSTEP = 4 * KL, KS = (CW + KSTEP - 1) / KSTEP;
+  static constexpr int NTMAP = (((CW + 15) / 16) + 1) & ~1;
+  static constexpr int UN = (BF16 && !HDR) ? 2 : 1;                   // n-tiles per output unit
+  static constexpr int NWV = BF16 ? NTMAP / 2 : NTMAP;                // waves = units of a map layer (>= KS)
+  static constexpr int HTILES = tower_hdr_tiles(CW, BF16);            // most n-tiles a header segment has
+  static constexpr int MAXU = HDR ? (HTILES + NWV - 1) / NWV : 1;     // units per wave
+  // halo pixel pitch: a multiple of 16 bytes that is 2 mod 4 in 16-byte units.  ds_read_b128 is served in the lane groups
+  // {0-3, 12-15, 20-27} ... (MI355X_MICROARCH.md, LDS): patch rows 0 and 3 of one channel group with rows 1 and 2 of the next; with
+  // column-major halo slots (slot = hx * 10 + hy) those 16 reads fall on 16 different 16-byte bank slots for every tap exactly
+  // when the pitch is 2, 6, 10 or 14 (mod 16) units (enumerated); the natural +16-byte pad (21 units at width 160) is 2-way
+  static constexpr int PU = CW * ES / 16, HP = (PU + (6 - PU % 4) % 4) * 16 / ES;
+  static constexpr int BIAS = (HDR ? HTILES : NTMAP) * 16;
+  // Image slots: the hardware places a workgroup as ceil(waves / 4) waves on EVERY SIMD, so a 5-wave workgroup at 3 waves per
+  // SIMD (<= 168 VGPRs) is alone on its CU (traced: 256 workgroups resident, not 512).  Such layers run TWO images side by
+  // side in one 10-wave workgroup - two independent halves (own halo, own fragments) sharing bias, depthwise weights and barriers.
+  static constexpr int IPAR = NWV == 5 ? 2 : 1;
+  static constexpr size_t OFF_XA = ((size_t)BIAS + 9 * CW) * 4;          // [BIAS] f32 bias | [9][CW] f32 depthwise weights | per slot: fragments | halo
+  static constexpr size_t XA_BYTES = (size_t)4 * KS * 64 * 16, HALO_BYTES = (size_t)100 * HP * ES, SLOT_BYTES = XA_BYTES + HALO_BYTES;
+  static constexpr size_t LDS = OFF_XA + IPAR * SLOT_BYTES;
+  static_assert(NWV >= KS, "one depthwise k-step per wave");
+};
+
+template <bool BF16, int CW, bool HDR>
+__global__ __launch_bounds__((CoopCfg<BF16, CW, HDR>::IPAR * CoopCfg<BF16, CW, HDR>::NWV * 64), (CoopCfg<BF16, CW, HDR>::NWV <= 5 ? 3 : 1)) void tower_coop_kernel(const SepSeg* __restrict__ segs, const int* __restrict__ tile_seg, int B, int ipb) {
+  typedef Frag<BF16> F;
+  typedef typename F::raw raw_t;
+  typedef typename Vec8<BF16>::elem T;
+  typedef CoopCfg<BF16, CW, HDR> Cfg;
+  constexpr int KL = Cfg::KL, KSTEP = Cfg::KSTEP, KS = Cfg::KS, ES = Cfg::ES, HP = Cfg::HP, NWV = Cfg::NWV, UN = Cfg::UN, MAXU = Cfg::MAXU;
+  constexpr bool KFULL = CW % KSTEP == 0;
+  constexpr int IPAR = Cfg::IPAR, NTHA = IPAR * NWV * 64;             // image slots; threads of the whole workgroup
+  constexpr int NTH = NWV * 64, CPP = CW / KL, NV = (100 * CPP + NTH - 1) / NTH, PPJ = NTH / CPP;   // PPJ: halo pixels one pass of the threads covers
+  static_assert(NTH % CPP == 0, "a thread keeps its channel vector from pass to pass");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  HEP_POISON(smem, Cfg::LDS);
+#ifdef HEP_TOWER_TRACE
+  unsigned long long stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  TSTAMP_NOWAIT(0);
+#endif
+  float* bias_s = reinterpret_cast<float*>(smem);
+  float* wdw_s = bias_s + Cfg::BIAS;
+
+  int bxl, byl;
+  xcd_remap2(blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, &bxl, &byl);     // neighbouring tiles of a map on one XCD (shared halo lines)
+  const int si = __builtin_amdgcn_readfirstlane(tile_seg[bxl]);
+  const SepSeg* __restrict__ sg = segs + si;
+  const int h = sg->h, w = sg->w, tiles_x = sg->tiles_x, tilesN = sg->tilesN;
+  const int wva = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int iw = IPAR > 1 ? (wva >= NWV ? 1 : 0) : 0, wv = wva - iw * NWV, tid = (int)threadIdx.x - iw * NTH;   // image slot; wave / thread within it
+  raw_t* xa_s = reinterpret_cast<raw_t*>(smem + Cfg::OFF_XA + iw * Cfg::SLOT_BYTES);
+  T* halo = reinterpret_cast<T*>(smem + Cfg::OFF_XA + iw * Cfg::SLOT_BYTES + Cfg::XA_BYTES);
+  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+  const GLOBAL T* W = (const GLOBAL T*)sg->wpw;
+  const int kdw = min(wv, KS - 1);                      // this wave's depthwise k-step (waves >= KS: none)
+  const bool dw_wave = wv < KS, kok_dw = KFULL || kdw * KSTEP + KL * g < CW;
+
+  // ---- this wave's weights -> registers (every load issued before the first use) ----
+  raw_t wfr[MAXU * UN][KS];
+#pragma unroll
+  for (int u = 0; u < MAXU; u++)
+#pragma unroll
+    for (int j = 0; j < UN; j++) {
+      const int nt = (wv + u * NWV) * UN + j;
+      const GLOBAL T* wr = W + (int64_t)(min(nt, tilesN - 1) * 16 + r) * CW;
+#pragma unroll
+      for (int ks = 0; ks < KS; ks++) {
+        const bool kok = KFULL || ks * KSTEP + KL * g < CW;
+        wfr[u * UN + j][ks] = *(const GLOBAL raw_t*)(wr + (kok ? ks * KSTEP + KL * g : 0));
+        if (!KFULL && !kok) wfr[u * UN + j][ks] = raw_t{};
+      }
+    }
+  // depthwise weights: staged once (swizzled for the packed FMAs); a wave re-reads the 9 x KL of ITS (k-step, lane group) at the
+  // start of every image's depthwise phase - 18 LDS reads per image instead of 72 registers held through the MFMA phase
+  for (int i = threadIdx.x; i < 9 * CW / 4; i += NTHA) reinterpret_cast<f32x4*>(wdw_s)[i] = F::swz(((const GLOBAL f32x4*)sg->wdw)[i]);
+  const float* wdl = wdw_s + (kok_dw ? kdw * KSTEP + KL * g : 0);
+  for (int i = threadIdx.x; i < tilesN * 4; i += NTHA) reinterpret_cast<f32x4*>(bias_s)[i] = ((const GLOBAL f32x4*)sg->bias)[i];   // visible after the first barrier
+
+  // ---- geometry: the tile, its 10x10 halo (column-major slots: slot = hx * 10 + hy), the four 4x4 patches = m-tiles ----
+  const int t = bxl - sg->tile_begin;
+  const int ty = t / tiles_x, tx = t - ty * tiles_x, Y0 = ty * 8, X0 = tx * 8;
+  const int b0 = byl * ipb + iw, nall = min(ipb, B - byl * ipb);        // this slot's images: b0, b0 + IPAR, ...
+  const int nimg = (nall - iw + IPAR - 1) / IPAR, nloop = (nall + IPAR - 1) / IPAR;   // (every wave runs nloop iterations: the barriers are shared)
+  const int img_elems = h * w * CW;
+  const GLOBAL T* Ximg = (const GLOBAL T*)sg->src[0] + (int64_t)b0 * img_elems;
+  constexpr uint32_t OOB = 0x80000000u;
+  uint32_t hoff[NV];
+  const int hp0 = tid / CPP, hch = tid - hp0 * CPP;     // pass j: halo pixel hp0 + j * PPJ, channel vector hch
+#pragma unroll
+  for (int j = 0; j < NV; j++) {
+    const int hp = hp0 + j * PPJ, hx = hp / 10, hy = hp - hx * 10;
+    const int iy = Y0 - 1 + hy, ix = X0 - 1 + hx;
+    const bool ok = hp < 100 && iy >= 0 && iy < h && ix >= 0 && ix < w;
+    hoff[j] = ok ? (uint32_t)((iy * w + ix) * CW + hch * KL) * ES : OOB;     // out of range: the hardware returns the zero padding
+  }
+  T* hdst0 = halo + hp0 * HP + hch * KL;
+  int toff[9];
+#pragma unroll
+  for (int q = 0; q < 9; q++) toff[q] = (((r & 3) + q % 3) * 10 + (r >> 2) + q / 3) * HP + (kok_dw ? kdw * KSTEP + KL * g : 0);
+  bool pok[4];                                           // (uniform) the 4x4 patch p has pixels inside the map
+#pragma unroll
+  for (int p = 0; p < 4; p++) pok[p] = Y0 + (p >> 1) * 4 < h && X0 + (p & 1) * 4 < w;
+  raw_t hv[NV];
+  auto load_halo = [&](int bi) {
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)(Ximg + (int64_t)bi * IPAR * img_elems), 0, img_elems * ES, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < NV; j++) hv[j] = __builtin_bit_cast(raw_t, __builtin_amdgcn_raw_buffer_load_b128(xrs, hoff[j], 0, 0));
+  };
+  if (nimg > 0) load_halo(0);
+  const int N = sg->N, act = sg->act;
+  TSTAMP_NOWAIT(1);                    // weights, staging and the first halo issued
+
+#pragma unroll 1
+  for (int bi = 0; bi < nloop; bi++) {
+    const int b = b0 + bi * IPAR;
+    const bool have = bi < nimg;                       // (uniform per wave) this slot has an image in this iteration
+#pragma unroll
+    for (int j = 0; j < NV; j++) if (have && hp0 + j * PPJ < 100) *reinterpret_cast<raw_t*>(hdst0 + j * PPJ * HP) = hv[j];
+#ifdef HEP_TOWER_TRACE
+    if (bi == 0) TSTAMP(2);            // first halo arrived and parked
+#endif
+    __syncthreads();                                   // halo (and, first image, bias and depthwise weights) in LDS
+#ifdef HEP_TOWER_TRACE
+    if (bi == 0) TSTAMP_NOWAIT(3);
+#endif
+    if (dw_wave && have) {
+      // one row of taps at a time over all four patches: 3 x KL weights + 4 accumulators live, not 9 x KL weights
+      typename F::Acc acc[4];
+#pragma unroll
+      for (int p = 0; p < 4; p++) F::zero(acc[p]);
+#pragma unroll
+      for (int qr = 0; qr < 3; qr++) {
+        f32x4 wa[3], wb[3];
+#pragma unroll
+        for (int qc = 0; qc < 3; qc++) {
+          wa[qc] = *reinterpret_cast<const f32x4*>(wdl + (qr * 3 + qc) * CW);
+          wb[qc] = BF16 ? *reinterpret_cast<const f32x4*>(wdl + (qr * 3 + qc) * CW + 4) : wa[qc];
+        }
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+          if (pok[p]) {                                                      // (uniform) patch inside the map
+            const T* hb = halo + ((p & 1) * 40 + (p >> 1) * 4) * HP;
+#pragma unroll
+            for (int qc = 0; qc < 3; qc++) F::fma_tap_r(acc[p], *reinterpret_cast<const raw_t*>(hb + toff[qr * 3 + qc]), wa[qc], wb[qc]);
+          }
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < 4; p++) {
+        if (pok[p]) {
+          raw_t xv = F::pack(acc[p]);
+          if (!KFULL && !kok_dw) xv = raw_t{};          // k >= CW: the operand must be exactly zero
+          xa_s[(p * KS + kdw) * 64 + lane] = xv;
+        }
+      }
+    }
+#ifdef HEP_TOWER_TRACE
+    if (bi == 0) TSTAMP(4);            // depthwise done
+#endif
+    __syncthreads();                                   // operand fragments complete; the halo may be overwritten
+#ifdef HEP_TOWER_TRACE
+    if (bi == 0) TSTAMP_NOWAIT(5);
+#endif
+    // the next image's halo flies during the MFMA phase (issued here, not before the depthwise phase: its 7 vectors per lane
+    // next to the 72 depthwise weights spilled)
+    if (bi + 1 < nimg) load_halo(bi + 1);
+#pragma unroll 1
+    for (int p = 0; p < (have ? 4 : 0); p++) {
+      const int y = Y0 + (p >> 1) * 4 + (r >> 2), x = X0 + (p & 1) * 4 + (r & 3);
+      if (!(Y0 + (p >> 1) * 4 < h && X0 + (p & 1) * 4 < w)) continue;   // (p is a run-time index here)
+      const bool pix_ok = y < h && x < w;
+      raw_t xv[KS];
+#pragma unroll
+      for (int ks = 0; ks < KS; ks++) xv[ks] = xa_s[(p * KS + ks) * 64 + lane];
+      if constexpr (!HDR) {
+        constexpr int RUN = 4 * Cfg::NTMAP;
+        GLOBAL T* O = (GLOBAL T*)sg->out + (int64_t)b * sg->out_bstride + sg->out_off + ((int64_t)y * w + x) * sg->out_rowstride;
+        const int ch = g * RUN + wv * UN * 4;
+        f32x4 acc[UN];
+#pragma unroll
+        for (int j = 0; j < UN; j++) acc[j] = *reinterpret_cast<const f32x4*>(bias_s + ch + 4 * j);
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++)
+#pragma unroll
+          for (int j = 0; j < UN; j++) acc[j] = F::mma(wfr[j][ks], xv[ks], acc[j]);
+        if (pix_ok && ch < N) {
+          float v[4 * UN];
+#pragma unroll
+          for (int j = 0; j < UN; j++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) v[4 * j + q] = acc[j][q];
+          if (act == ACT_SWISH) {
+#pragma unroll
+            for (int q = 0; q < 4 * UN; q++) v[q] = swish_t<BF16>(v[q]);
+          } else if (act == ACT_SIGMOID) {
+#pragma unroll
+            for (int q = 0; q < 4 * UN; q++) v[q] = sigmoid_t<BF16>(v[q]);
+          }
+          if constexpr (BF16) {
+            u32x4 pk;
+#pragma unroll
+            for (int e = 0; e < 4; e++) pk[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
+            if (ch + 8 <= N) *(GLOBAL u32x4*)(O + ch) = pk;
+            else *(GLOBAL u32x2*)(O + ch) = (u32x2){pk[0], pk[1]};
+          } else {
+            *(GLOBAL f32x4*)(O + ch) = (f32x4){v[0], v[1], v[2], v[3]};
+          }
+        }
+      } else {
+        typedef float __attribute__((ext_vector_type(4), aligned(4))) f32x4_u;
+        const int kin = sg->col_kin, kout = sg->col_kout, coff = sg->col_off, nbase = sg->n_base;
+        GLOBAL float* O = (GLOBAL float*)sg->out + (int64_t)b * sg->out_bstride + sg->out_off + ((int64_t)y * w + x) * sg->out_rowstride;
+        const bool contiguous = kin == kout && coff == 0;
+#pragma unroll
+        for (int u = 0; u < MAXU; u++) {
+          const int nt = wv + u * NWV;
+          if (nt >= tilesN) continue;                   // (uniform)
+          const int n = nt * 16 + 4 * g;
+          f32x4 acc = *reinterpret_cast<const f32x4*>(bias_s + n);
+#pragma unroll
+          for (int ks = 0; ks < KS; ks++) acc = F::mma(wfr[u][ks], xv[ks], acc);
+          if (pix_ok && n < N) {
+            if (act == ACT_SIGMOID) {
+#pragma unroll
+              for (int q = 0; q < 4; q++) acc[q] = sigmoid_t<BF16>(acc[q]);
+            } else if (act == ACT_SWISH) {
+#pragma unroll
+              for (int q = 0; q < 4; q++) acc[q] = swish_t<BF16>(acc[q]);
+            }
+            if (contiguous && n + 4 <= N) {
+              *(GLOBAL f32x4_u*)(O + nbase + n) = acc;
+            } else {
+#pragma unroll
+              for (int q = 0; q < 4; q++) {
+                const int nn = nbase + n + q;
+                if (n + q < N) O[(nn / kin) * kout + nn % kin + coff] = acc[q];
+              }
+            }
+          }
+        }
+      }
+    }
+#ifdef HEP_TOWER_TRACE
+    if (bi == 0) TSTAMP_NOWAIT(6);     // first image: MFMA phase done, stores issued
+#endif
+  }   // image loop
+#ifdef HEP_TOWER_TRACE
+  TSTAMP(7);                           // all images done, stores acknowledged
+  if (g_tower_trace && lane == 0 && (g_tower_trace_maps != 0) == !HDR) {
+    unsigned long long* o = g_tower_trace + ((size_t)(byl * gridDim.x + bxl) * NWV * IPAR + (threadIdx.x >> 6)) * 8;
+    for (int i = 0; i < 8; i++) o[i] = stamps[i];
+  }
+#endif
+}
+
 static const int kTowerWidths[] = {64, 88, 112, 160, 224, 288, 384};   // BiFPN widths of phi 0..6 (arch.py)
 
 int tower_supports(int C) {
@@ -407,8 +686,37 @@ static void launch_one(const SepArgs& a, dim3 grid, hipStream_t s, int ipb) {
 template <int CW>
 static void launch_w(const SepArgs& a, dim3 grid, hipStream_t s, int ipb) {
   const bool hdr = a.direct == 2;
+  if (a.coop) {
+    if (a.bf16) { if (hdr) launch_coop<true, CW, true>(a, grid, s, ipb); else launch_coop<true, CW, false>(a, grid, s, ipb); }
+    else { if (hdr) launch_coop<false, CW, true>(a, grid, s, ipb); else launch_coop<false, CW, false>(a, grid, s, ipb); }
+    return;
+  }
   if (a.bf16) { if (hdr) launch_one<true, CW, true>(a, grid, s, ipb); else launch_one<true, CW, false>(a, grid, s, ipb); }
   else { if (hdr) launch_one<false, CW, true>(a, grid, s, ipb); else launch_one<false, CW, false>(a, grid, s, ipb); }
+}
+
+// widths / dtypes the cooperative form is instantiated for
+template <bool BF16, int CW> struct CoopBuilt { static constexpr bool value = BF16 ? CW >= 160 : CW == 64; };
+int tower_coop_supported(int C, int bf16) {
+  if (bf16) return C == 160 || C == 224 || C == 288 || C == 384;
+  return C == 64;
+}
+
+template <bool BF16, int CW, bool HDR>
+static void launch_coop(const SepArgs& a, dim3 grid, hipStream_t s, int ipb) {
+  if constexpr (CoopBuilt<BF16, CW>::value) {
+    typedef CoopCfg<BF16, CW, HDR> Cfg;
+    hipLaunchKernelGGL((tower_coop_kernel<BF16, CW, HDR>), grid, dim3(Cfg::IPAR * Cfg::NWV * 64), Cfg::LDS, s, a.segs, a.tile_seg, a.B, ipb);
+  }
+}
+
+template <bool BF16, int CW>
+static int prepare_coop() {
+  if constexpr (CoopBuilt<BF16, CW>::value) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(tower_coop_kernel<BF16, CW, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024) != hipSuccess) return -1;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(tower_coop_kernel<BF16, CW, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024) != hipSuccess) return -1;
+  }
+  return 0;
 }
 
 template <int CW>
@@ -417,7 +725,7 @@ static int prepare_w() {
                         reinterpret_cast<const void*>(tower_kernel<false, CW, true>), reinterpret_cast<const void*>(tower_kernel<false, CW, false>)};
   for (const void* f : fns)
     if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024) != hipSuccess) return -1;
-  return 0;
+  return prepare_coop<true, CW>() | prepare_coop<false, CW>();
 }
 
 // raises the dynamic-LDS limit of every instantiation (call once per device)
@@ -445,6 +753,7 @@ void launch_tower(const SepArgs& a, hipStream_t s) {
   const char* ipb_e = getenv("HEP_TOWER_IPB"); const int ipb_env = ipb_e ? atoi(ipb_e) : 0;
   int ipb = ipb_env > 0 ? ipb_env : 1;
   if (ipb_env <= 0) while (ipb < 4 && (int64_t)a.total_tiles * ((a.B + 2 * ipb - 1) / (2 * ipb)) >= 900) ipb *= 2;
+  if (a.coop && ipb_env <= 0) ipb = 4;       // cooperative form: weights in registers per workgroup, two image slots where a workgroup has five waves
   ipb = std::min(ipb, a.B);
   const dim3 grid(a.total_tiles, (a.B + ipb - 1) / ipb);
   switch (a.C) {

@@ -462,7 +462,8 @@ ALT_PLANS = [
     ({"HEP_SE_MAXMB": "0"}, lambda ks: sum("se_finish_kernel" in y for _, y in ks) >= 12),
     ({"HEP_SE_MAXMB": "1000"}, lambda ks: not any("se_finish_kernel" in y for _, y in ks)),
     ({"HEP_PWG": "0", "HEP_PW_MT2": "0"}, lambda ks: not any("pw_group_kernel" in y for _, y in ks)),
-    ({"HEP_TOWER": "0"}, lambda ks: not any("tower_kernel" in y for _, y in ks)),
+    ({"HEP_TOWER": "0"}, lambda ks: not any("tower_" in y for _, y in ks)),
+    ({"HEP_TOWER_COOP": "0"}, lambda ks: any(y.startswith("tower_kernel<") for _, y in ks) and not any("tower_coop_kernel" in y for _, y in ks)),   # wave-per-patch heads
     ({"HEP_XBF": "0"}, lambda ks: not any("xbf_kernel" in y for _, y in ks)),
     ({"HEP_XBF_GENERIC": "1"}, lambda ks: any("xbf_kernel" in y for _, y in ks) and all(y.endswith(", 0, 0>") for _, y in ks if "xbf_kernel" in y)),
     ({"HEP_XBF_TPW": "3"}, None),
@@ -524,13 +525,16 @@ def test_default_fp32_plan_runs_its_chains_in_lds(api):
     syms = [y for _, y in _plan_syms(s, 2)]
     s.close()
     assert sum(y.startswith("chain_kernel<false") for y in syms) == 4 and "chain_kernel<false, 1>" in syms and not any("sep_kernel<false, 2" in y for y in syms), syms
+    # ... and every head layer on the cooperative tower kernel (one halo per workgroup, weights in registers)
+    assert sum(y.startswith("tower_coop_kernel<false, 64") for y in syms) == 4 and not any(y.startswith("tower_kernel<") for y in syms), syms
 
 
-@pytest.mark.parametrize("phi,env", [(1, {"HEP_SEP_WLDS": "0"}), (3, {"HEP_SEP_WLDS": "0"}), (0, {"HEP_CHAIN_STREAM": "1"}), (0, {"HEP_CHAIN_STREAM": "2"}), (3, {"HEP_CHAIN_WGLOBAL": "0"})])
+@pytest.mark.parametrize("phi,env", [(1, {"HEP_SEP_WLDS": "0"}), (3, {"HEP_SEP_WLDS": "0"}), (0, {"HEP_CHAIN_STREAM": "1"}), (0, {"HEP_CHAIN_STREAM": "2"}), (3, {"HEP_CHAIN_WGLOBAL": "0"}), (3, {"HEP_TOWER_COOP": "0"})])
 def test_bf16_plan_variants_are_bit_identical(api, phi, env, monkeypatch):
     """A plan choice that only moves data differently - BiFPN nodes wider than 64 channels with their pointwise weights staged
     in LDS or fetched per fragment (widths 88 and 160), LDS-resident node chains with all node weights resident, streamed by
-    LDS-DMA or with their pointwise fragments straight from global memory (width 64; width 160 against the k_sep.hip chains) - leaves the arithmetic and its order alone: bf16 sessions must agree bit for bit."""
+    LDS-DMA or with their pointwise fragments straight from global memory (width 64; width 160 against the k_sep.hip chains), head
+    layers at width 160 on the cooperative tower kernel or the wave-per-patch one - leaves the arithmetic and its order alone: bf16 sessions must agree bit for bit."""
     size, batch = 256, 2
     sd = api["sd"](phi, 5)
     x = torch.from_numpy(seeded_input((batch, 3, size, size), 23)).cuda()
