@@ -25,14 +25,22 @@ __device__ __forceinline__ float apply_act(float x, int act) {
   return act == 1 ? swishf(x) : (act == 2 ? sigmoidf(x) : x);
 }
 // bf16 kernels use v_rcp_f32 (1 ulp) instead of the IEEE division sequence (~10 instructions): the
-// result is rounded to bf16 (8 bits) right after.  The fp32 parity mode keeps the exact division.
+// result is rounded to bf16 (8 bits) right after.
+// fp32 sessions: v_rcp_f32 + one Newton step (<= 1 ulp of 1 / d, 4 instructions) in place of the division sequence (round 4:
+// 25.7k -> 26.5k frames/s; ADD against the reference unchanged at 0.003 mm).  The reference's own x * sigmoid(x) rounds twice
+// (efficientnet/utils.py:57-59), so neither form is bit-identical to it; both sit ~1 ulp from the exact quotient.
+__device__ __forceinline__ float rcp_newton(float d) {
+  d = fminf(d, 0x1p126f);                       // e^-x overflowed: keep the step finite (the product is ~1e-37 either way)
+  const float r = __builtin_amdgcn_rcpf(d);
+  return fmaf(fmaf(-d, r, 1.0f), r, r);
+}
 template <bool FAST> __device__ __forceinline__ float swish_t(float x) {
   const float d = 1.0f + __expf(-x);
-  return FAST ? x * __builtin_amdgcn_rcpf(d) : x / d;
+  return x * (FAST ? __builtin_amdgcn_rcpf(d) : rcp_newton(d));
 }
 template <bool FAST> __device__ __forceinline__ float sigmoid_t(float x) {
   const float d = 1.0f + __expf(-x);
-  return FAST ? __builtin_amdgcn_rcpf(d) : 1.0f / d;
+  return FAST ? __builtin_amdgcn_rcpf(d) : rcp_newton(d);
 }
 template <bool FAST> __device__ __forceinline__ float apply_act_t(float x, int act) {
   return act == 1 ? swish_t<FAST>(x) : (act == 2 ? sigmoid_t<FAST>(x) : x);
