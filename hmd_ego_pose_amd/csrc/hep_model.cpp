@@ -840,7 +840,8 @@ struct Planner {
     o.sep.coop = 0;
     if (direct && tower_coop_supported(C, s->dtype != 0)) {
       const char* e = getenv("HEP_TOWER_COOP");
-      o.sep.coop = e ? (atoi(e) != 0) : 1;
+      // (the bf16 header launch stays on tower_kernel: 113 against 118 us at width 160 - its segments have 1-10 n-tiles for five waves)
+      o.sep.coop = e ? (atoi(e) != 0) : (direct == 1 || s->dtype == 0);
     }
     bool all_maps = true;
     for (const SegSpec& sp : specs) all_maps = all_maps && sp.out_t >= 0 && sp.N == C;
