@@ -293,6 +293,10 @@ constexpr int tower_hdr_tiles(int C, bool bf16) {
   const long t = room / (16 * wp * es + 64);                            // 16 weight rows + 16 bias floats per n-tile
   return t < 1 ? 1 : (t > 12 ? 12 : (int)t);
 }
+// ... of the cooperative form (tower_coop_kernel: a wave holds the weight fragments of its n-tiles in registers): bf16 at width 64 takes
+// a whole 567-column hand header (36 tiles, 9 per wave x 2 k-steps x 4 registers) as ONE segment - the depthwise conv of the
+// head's last map and its input are then computed / read once, not once per 12-tile chunk
+constexpr int tower_coop_hdr_tiles(int C, bool bf16) { return bf16 && C == 64 ? 36 : tower_hdr_tiles(C, bf16); }
 int tower_prepare(void);         // raises the dynamic-LDS limit of the tower kernels (call once per device)
 int tower_coop_supported(int C, int bf16);   // widths / dtypes tower_coop_kernel is instantiated for
 int tower_supports(int C);       // BiFPN widths k_tower.hip is instantiated for

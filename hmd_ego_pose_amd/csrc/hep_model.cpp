@@ -745,6 +745,7 @@ struct Planner {
     int out_t;                       // dtype tensor, or -1 for a head output
     int head_out; int col_kin, col_kout, col_off, out_k;   // head output index 0..4 and column mapping
   };
+  static int tower_coop_default_bf16_64(int direct) { (void)direct; return 0; }   // (set by measurement below)
   int sep_tile_side() const {
     SepArgs probe; memset(&probe, 0, sizeof probe);
     sep_lds_layout(s->arch.fpn_w, s->dtype, 8, 96, s->arch.fpn_w, &probe);
@@ -771,7 +772,18 @@ struct Planner {
       }
       if (simple && (maps || heads)) direct = maps ? 1 : 2;
     }
-    const int chunk_cols_out = (direct ? tower_hdr_tiles(C, s->dtype != 0) : SEP_MAX_TILES_N) * 16;   // head outputs are split into column chunks, maps never
+    // cooperative tower form (tower_coop_kernel) wherever it is instantiated and measured faster: bf16 map layers from width 160, where
+    // the wave-private halos of tower_kernel no longer fit (phi 3 @ 512 b8: 5.02k -> 5.15k frames/s; the bf16 header launch there stays
+    // on tower_kernel: 113 against 118 us - its segments have 1-10 n-tiles for five waves), fp32 at width 64 (24.7k -> 25.7k).
+    // HEP_TOWER_COOP: 0 off, 1 on wherever instantiated, 2 map layers only, 3 headers only
+    int coop = 0;
+    if (direct && tower_coop_supported(C, s->dtype != 0)) {
+      const char* e = getenv("HEP_TOWER_COOP");
+      const int v = e ? atoi(e) : -1;
+      if (v < 0) coop = s->dtype == 0 || (C >= 160 ? direct == 1 : tower_coop_default_bf16_64(direct));
+      else coop = v == 1 || (v == 2 && direct == 1) || (v == 3 && direct == 2);
+    }
+    const int chunk_cols_out = (direct ? (coop ? tower_coop_hdr_tiles(C, s->dtype != 0) : tower_hdr_tiles(C, s->dtype != 0)) : SEP_MAX_TILES_N) * 16;   // head outputs are split into column chunks, maps never
     int tiles_n_max = 0;
     for (size_t i = 0; i < specs.size(); i++) {
       const SegSpec& sp = specs[i];
@@ -835,14 +847,7 @@ struct Planner {
     o.sep.nseg = (int)o.segs.size(); o.sep.total_tiles = tile_begin; o.sep.bf16 = s->dtype; o.sep.C = C;
     o.sep.chain = chain && o.segs.size() > 1;
     o.sep.direct = direct;
-    // cooperative tower form wherever it is instantiated: bf16 from width 160, where the wave-private halos of tower_kernel no
-    // longer fit (phi 3 @ 512 b8: 5.02k -> 5.14k frames/s), and fp32 at width 64 (24.7k -> 25.7k); HEP_TOWER_COOP=0 turns it off
-    o.sep.coop = 0;
-    if (direct && tower_coop_supported(C, s->dtype != 0)) {
-      const char* e = getenv("HEP_TOWER_COOP");
-      // (the bf16 header launch stays on tower_kernel: 113 against 118 us at width 160 - its segments have 1-10 n-tiles for five waves)
-      o.sep.coop = e ? (atoi(e) != 0) : (direct == 1 || s->dtype == 0);
-    }
+    o.sep.coop = coop;
     bool all_maps = true;
     for (const SegSpec& sp : specs) all_maps = all_maps && sp.out_t >= 0 && sp.N == C;
     sep_lds_layout(C, s->dtype, ts_max, cols_f32, cols_map, &o.sep, (chain || specs.size() == 1) && all_maps && !direct && !(getenv("HEP_SEP_WLDS") && atoi(getenv("HEP_SEP_WLDS")) == 0));
