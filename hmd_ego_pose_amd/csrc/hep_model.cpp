@@ -745,7 +745,10 @@ struct Planner {
     int out_t;                       // dtype tensor, or -1 for a head output
     int head_out; int col_kin, col_kout, col_off, out_k;   // head output index 0..4 and column mapping
   };
-  static int tower_coop_default_bf16_64(int direct) { (void)direct; return 0; }   // (set by measurement below)
+  // bf16 at width 64 (instantiated for the A/B, bit-identical): map layers 16 against 13.3 us, the header launch - the hand head as one
+  // 36-tile segment on eight waves - 47.6 against 27.3 us; 49.0k against 49.7k frames/s with both: tower_kernel's four wave-private
+  // halos fit at this width and it has no barrier per image
+  static int tower_coop_default_bf16_64(int direct) { (void)direct; return 0; }
   int sep_tile_side() const {
     SepArgs probe; memset(&probe, 0, sizeof probe);
     sep_lds_layout(s->arch.fpn_w, s->dtype, 8, 96, s->arch.fpn_w, &probe);
