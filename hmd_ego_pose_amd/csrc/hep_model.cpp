@@ -827,6 +827,7 @@ struct Planner {
         }
         sg.N = Nc; sg.tilesN = tilesN; sg.act = sp.act; sg.n_base = n0;
         sg.ts = ts_pick;   // 8; 16x16 tiles measured slower (3 dependent gather rounds per lane, 1 workgroup per CU)
+        if (const char* e = getenv("HEP_SEP_TS4_MAXHW")) if (!direct && !chain && specs.size() == 1 && hw <= atoi(e)) sg.ts = 4;   // latency knob: 4x4 tiles on levels with few 8x8 tiles (one batch in flight +1-3 %, four in flight -1-4 %: DESIGN section 2)
         ts_max = std::max(ts_max, sg.ts);
         if (sp.out_t >= 0) cols_map = std::max(cols_map, Nc); else cols_f32 = std::max(cols_f32, Nc);
         sg.tiles_x = (hw + sg.ts - 1) / sg.ts; sg.tiles_y = sg.tiles_x; sg.tile_begin = tile_begin; sg.tiles_x_rcp = rcp_u32(sg.tiles_x);

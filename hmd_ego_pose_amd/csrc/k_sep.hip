@@ -387,7 +387,7 @@ void sep_lds_layout(int C, int bf16, int ts, int max_cols_f32, int max_cols_map,
   // that nothing overlapped: 15-28 us per node at phi 3 @ 512 for 1.5-24 MB.)
   a->off_wpw = 0;
   const size_t wrows = (size_t)((C + 15) / 16) * 16, wbytes = wrows * (C + pad) * es;      // whole n-tiles: widths like 88 end in a half-used one
-  if (stage_w && bf16 && C > 64 && ts == 8 && wrows * (C / 8) <= 4 * 1024 && a->lds_bytes + wbytes <= 159 * 1024) { a->off_wpw = (a->lds_bytes + 15) & ~(size_t)15; a->lds_bytes = a->off_wpw + wbytes; }
+  if (stage_w && bf16 && C > 64 && (ts == 8 || ts == 4) && wrows * (C / 8) <= 4 * 1024 && a->lds_bytes + wbytes <= 159 * 1024) { a->off_wpw = (a->lds_bytes + 15) & ~(size_t)15; a->lds_bytes = a->off_wpw + wbytes; }
 }
 
 int sep_prepare(void) {
