@@ -42,6 +42,38 @@ template <bool FAST> __device__ __forceinline__ float sigmoid_t(float x) {
   const float d = 1.0f + __expf(-x);
   return FAST ? __builtin_amdgcn_rcpf(d) : rcp_newton(d);
 }
+// Two activations at a time with the multiplies and the add as packed instructions (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32: two
+// lanes of fp32 per issue slot) - bit-identical to the scalar forms above (same IEEE operations on the same operands), one issue
+// slot fewer per value in bf16 sessions (7 -> 5.5 of 4 cycles; the two transcendentals stay 8 each), 2.5 fewer in fp32.  The chip's
+// VALU pipes are >= 50 % busy with four batches in flight (profiles/r04/d_valu_mix.json), swish is ~a quarter of that.
+template <bool FAST> __device__ __forceinline__ f32x2_t rcp2_t(f32x2_t d) {
+  if (FAST) return (f32x2_t){__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+  d = (f32x2_t){fminf(d[0], 0x1p126f), fminf(d[1], 0x1p126f)};
+  const f32x2_t r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+  const f32x2_t e = __builtin_elementwise_fma(-d, r, (f32x2_t){1.0f, 1.0f});
+  return __builtin_elementwise_fma(e, r, r);
+}
+template <bool FAST> __device__ __forceinline__ f32x2_t sigmoid_den2(f32x2_t x) {      // 1 + e^-x
+  const f32x2_t t = x * (f32x2_t){-1.44269504088896340736f, -1.44269504088896340736f};
+  return (f32x2_t){__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + (f32x2_t){1.0f, 1.0f};
+}
+template <bool FAST, int N> __device__ __forceinline__ void swish_n(float* v) {
+  static_assert(N % 2 == 0, "pairs");
+#pragma unroll
+  for (int c = 0; c < N; c += 2) {
+    const f32x2_t x = {v[c], v[c + 1]};
+    const f32x2_t y = x * rcp2_t<FAST>(sigmoid_den2<FAST>(x));
+    v[c] = y[0]; v[c + 1] = y[1];
+  }
+}
+template <bool FAST, int N> __device__ __forceinline__ void sigmoid_n(float* v) {
+  static_assert(N % 2 == 0, "pairs");
+#pragma unroll
+  for (int c = 0; c < N; c += 2) {
+    const f32x2_t y = rcp2_t<FAST>(sigmoid_den2<FAST>((f32x2_t){v[c], v[c + 1]}));
+    v[c] = y[0]; v[c + 1] = y[1];
+  }
+}
 template <bool FAST> __device__ __forceinline__ float apply_act_t(float x, int act) {
   return act == 1 ? swish_t<FAST>(x) : (act == 2 ? sigmoid_t<FAST>(x) : x);
 }

@@ -261,8 +261,7 @@ __global__ __launch_bounds__(CHAIN_THREADS) void chain_kernel(ChainArgs a) {
 #pragma unroll
             for (int c = 0; c < 8; c++) v[c] = fmaf(s.fw, t[c], v[c]);
           }
-#pragma unroll
-          for (int c = 0; c < 8; c++) v[c] = swish_t<BF16>(v[c]);
+          swish_n<BF16, 8>(v);
         }
         V::store(halo, (int64_t)pos * CH + cg * 8, v);
       }

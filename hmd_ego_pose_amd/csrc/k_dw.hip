@@ -131,7 +131,8 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs a) {
         if (nt + 1 < NT && 32 * (nt >> 1) + 32 <= C) {            // a full pair: 8 consecutive channels per lane
           float v[8];
 #pragma unroll
-          for (int q = 0; q < 4; q++) { v[q] = swish_t<BF16>(acc[nt][q]); v[4 + q] = swish_t<BF16>(acc[nt + 1][q]); }
+          for (int q = 0; q < 4; q++) { v[q] = acc[nt][q]; v[4 + q] = acc[nt + 1][q]; }
+          swish_n<BF16, 8>(v);
           Vec8<BF16>::store(o, 32 * (nt >> 1) + 8 * g, v);
         } else {
 #pragma unroll
@@ -141,7 +142,8 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs a) {
               if (n < C) {
                 float v[4];
 #pragma unroll
-                for (int q = 0; q < 4; q++) v[q] = swish_t<BF16>(acc[nt + h][q]);
+                for (int q = 0; q < 4; q++) v[q] = acc[nt + h][q];
+                swish_n<BF16, 4>(v);
                 Vec8<BF16>::store4(o, n, v);
               }
             }
@@ -202,8 +204,7 @@ __global__ __launch_bounds__(256) void stem_valu_kernel(StemArgs a) {
 #pragma unroll
       for (int c = 0; c < 8; c++) acc[c] = fmaf(x[t], w[t * a.Cout + c], acc[c]);
     }
-#pragma unroll
-    for (int c = 0; c < 8; c++) acc[c] = swish_t<BF16>(acc[c]);
+    swish_n<BF16, 8>(acc);
     Vec8<BF16>::store(a.out, pix * a.Cout + cg * 8, acc);
   }
 }

@@ -293,7 +293,8 @@ __global__ __launch_bounds__(TS == 16 ? 1024 : 512) void mbf_kernel(MbfArgs a) {
               const int ri = row_of(m), pp_ = (r0 + ri) * PW + q0 + (m - ri * wi);
               float vv[4];
 #pragma unroll
-              for (int q = 0; q < 4; q++) vv[q] = swish_t<BF16>(acc[i][q] + bias[q]);
+              for (int q = 0; q < 4; q++) vv[q] = acc[i][q] + bias[q];
+              swish_n<BF16, 4>(vv);
               V::store4(e_s, (int64_t)pp_ * EP + n, vv);
             }
           }
@@ -447,7 +448,8 @@ __global__ __launch_bounds__(TS == 16 ? 1024 : 512) void mbf_kernel(MbfArgs a) {
                 const int ri = row_of(m), p = (r0 + ri) * PW + q0 + (m - ri * wi);   // tile position of inside pixel m
                 float v[4];
 #pragma unroll
-                for (int q = 0; q < 4; q++) v[q] = swish_t<BF16>(acc[q]);
+                for (int q = 0; q < 4; q++) v[q] = acc[q];
+                swish_n<BF16, 4>(v);
                 V::store4(e_s, (int64_t)p * EP + n, v);
               }
             }
@@ -506,7 +508,8 @@ __global__ __launch_bounds__(TS == 16 ? 1024 : 512) void mbf_kernel(MbfArgs a) {
             const int ri = row_of(m), p = (r0 + ri) * PW + q0 + (m - ri * wi);   // tile position of inside pixel m
             float v[4];
 #pragma unroll
-            for (int q = 0; q < 4; q++) v[q] = swish_t<BF16>(F8 ? fmaf(acc[q], ws[q], bias[q]) : acc[q] + bias[q]);
+            for (int q = 0; q < 4; q++) v[q] = F8 ? fmaf(acc[q], ws[q], bias[q]) : acc[q] + bias[q];
+            swish_n<BF16, 4>(v);
             V::store4(e_s, (int64_t)p * EP + n, v);
           }
         }
@@ -577,11 +580,17 @@ __global__ __launch_bounds__(TS == 16 ? 1024 : 512) void mbf_kernel(MbfArgs a) {
     if (oy < a.Ho && ox < a.Wo) {
       float v[8];
 #pragma unroll
-      for (int c = 0; c < 8; c++) { v[c] = swish_t<BF16>(acc0[c]); sum[c] += v[c]; }
+      for (int c = 0; c < 8; c++) v[c] = acc0[c];
+      swish_n<BF16, 8>(v);
+#pragma unroll
+      for (int c = 0; c < 8; c++) sum[c] += v[c];
       V::store(a.out, (((int64_t)b * a.Ho + oy) * a.Wo + ox) * a.Cexp + c0 + cg * 8, v);
       if (ox + 1 < a.Wo) {
 #pragma unroll
-        for (int c = 0; c < 8; c++) { v[c] = swish_t<BF16>(acc1[c]); sum[c] += v[c]; }
+        for (int c = 0; c < 8; c++) v[c] = acc1[c];
+        swish_n<BF16, 8>(v);
+#pragma unroll
+        for (int c = 0; c < 8; c++) sum[c] += v[c];
         V::store(a.out, (((int64_t)b * a.Ho + oy) * a.Wo + ox + 1) * a.Cexp + c0 + cg * 8, v);
       }
     }

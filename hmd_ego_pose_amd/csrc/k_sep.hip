@@ -116,8 +116,7 @@ __device__ __forceinline__ void gather_fuse(const SepSeg& sg, int b, int y, int 
     for (int c = 0; c < 8; c++) v[c] = fmaf(sg.fw[i], i == down ? pooled[c] : same[i].get(c), v[c]);
   }
   if (sg.pre_act) {
-#pragma unroll
-    for (int c = 0; c < 8; c++) v[c] = swish_t<BF16>(v[c]);
+    swish_n<BF16, 8>(v);
   }
 }
 

@@ -340,8 +340,7 @@ __global__ __launch_bounds__(256, BF16 ? 4 : 2) void tower_kernel(const SepSeg* 
 #pragma unroll
         for (int q = 0; q < 4; q++) { v[q] = acc0[q]; v[4 + q] = acc1[q]; }
         if (act == ACT_SWISH) {           // uniform: one branch per n-tile pair, not one per element
-#pragma unroll
-          for (int q = 0; q < 8; q++) v[q] = swish_t<BF16>(v[q]);
+          swish_n<BF16, 8>(v);
         } else if (act == ACT_SIGMOID) {
 #pragma unroll
           for (int q = 0; q < 8; q++) v[q] = sigmoid_t<BF16>(v[q]);
@@ -623,8 +622,7 @@ __global__ __launch_bounds__((CoopCfg<BF16, CW, HDR>::IPAR * CoopCfg<BF16, CW, H
 #pragma unroll
             for (int q = 0; q < 4; q++) v[4 * j + q] = acc[j][q];
           if (act == ACT_SWISH) {
-#pragma unroll
-            for (int q = 0; q < 4 * UN; q++) v[q] = swish_t<BF16>(v[q]);
+            swish_n<BF16, 4 * UN>(v);
           } else if (act == ACT_SIGMOID) {
 #pragma unroll
             for (int q = 0; q < 4 * UN; q++) v[q] = sigmoid_t<BF16>(v[q]);

@@ -334,7 +334,8 @@ __global__ __launch_bounds__(XT, KS == 3 ? 4 : 2) void xbf_kernel(XbfArgs a) {  
           if (n20 + u < nt_end && p < PIN) {
             float v[4];
 #pragma unroll
-            for (int q = 0; q < 4; q++) v[q] = swish_t<BF16>(acc[u][q]);
+            for (int q = 0; q < 4; q++) v[q] = acc[u][q];
+            swish_n<BF16, 4>(v);
             xfrag_t ev;
             if constexpr (BF16) { ev[0] = ins ? pack_bf16x2(v[0], v[1]) : 0u; ev[1] = ins ? pack_bf16x2(v[2], v[3]) : 0u; }
             else ev = ins ? (f32x4){v[0], v[1], v[2], v[3]} : (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -387,11 +388,17 @@ __global__ __launch_bounds__(XT, KS == 3 ? 4 : 2) void xbf_kernel(XbfArgs a) {  
         if (oy < a.Ho && ox < a.Wo) {
           float v[8];
 #pragma unroll
-          for (int c = 0; c < 8; c++) { v[c] = swish_t<BF16>(acc0[c]); sum[ci][c] += v[c]; }
+          for (int c = 0; c < 8; c++) v[c] = acc0[c];
+          swish_n<BF16, 8>(v);
+#pragma unroll
+          for (int c = 0; c < 8; c++) sum[ci][c] += v[c];
           V::store(out_b, (int64_t)((oy * a.Wo + ox) * Cexp), v);
           if (ox + 1 < a.Wo) {
 #pragma unroll
-            for (int c = 0; c < 8; c++) { v[c] = swish_t<BF16>(acc1[c]); sum[ci][c] += v[c]; }
+            for (int c = 0; c < 8; c++) v[c] = acc1[c];
+            swish_n<BF16, 8>(v);
+#pragma unroll
+            for (int c = 0; c < 8; c++) sum[ci][c] += v[c];
             V::store(out_b, (int64_t)((oy * a.Wo + ox + 1) * Cexp), v);
           }
         }

@@ -471,6 +471,7 @@ ALT_PLANS = [
     ({"HEP_SBF": "1"}, lambda ks: any("sbf_kernel" in y for _, y in ks)),
     ({"HEP_STEM_MFMA": "1"}, lambda ks: any(y.startswith("stem_kernel<") for _, y in ks)),
     ({"HEP_PW_NT2": "4"}, None),                       # (changes the tile only from batch 16 up)
+    ({"HEP_SEP_TS4_MAXHW": "16"}, None),               # (same kernels on 4x4 tiles: the launch list does not change)
 ]
 
 
@@ -530,13 +531,14 @@ def test_default_fp32_plan_runs_its_chains_in_lds(api):
 
 
 @pytest.mark.parametrize("phi,env", [(1, {"HEP_SEP_WLDS": "0"}), (3, {"HEP_SEP_WLDS": "0"}), (0, {"HEP_CHAIN_STREAM": "1"}), (0, {"HEP_CHAIN_STREAM": "2"}), (3, {"HEP_CHAIN_WGLOBAL": "0"}), (3, {"HEP_TOWER_COOP": "0"}), (3, {"HEP_TOWER_COOP": "1"}),
-                                     (0, {"HEP_TOWER_COOP": "0"}), (0, {"HEP_TOWER_COOP": "1"}), (0, {"HEP_TOWER_COOP": "2"}), (0, {"HEP_TOWER_COOP": "3"})])
+                                     (0, {"HEP_TOWER_COOP": "0"}), (0, {"HEP_TOWER_COOP": "1"}), (0, {"HEP_TOWER_COOP": "2"}), (0, {"HEP_TOWER_COOP": "3"}),
+                                     (3, {"HEP_SEP_TS4_MAXHW": "32"}), (0, {"HEP_SEP_TS4_MAXHW": "16"})])
 def test_bf16_plan_variants_are_bit_identical(api, phi, env, monkeypatch):
     """A plan choice that only moves data differently - BiFPN nodes wider than 64 channels with their pointwise weights staged
     in LDS or fetched per fragment (widths 88 and 160), LDS-resident node chains with all node weights resident, streamed by
     LDS-DMA or with their pointwise fragments straight from global memory (width 64; width 160 against the k_sep.hip chains), head
     layers at widths 64 and 160 on the cooperative tower kernel or the wave-per-patch one (map layers, headers or both; the hand
-    header as one 36-tile segment or three 12-tile chunks) - leaves the arithmetic and its order alone: bf16 sessions must agree bit for bit."""
+    header as one 36-tile segment or three 12-tile chunks), BiFPN nodes of the small levels on 4x4 tiles - leaves the arithmetic and its order alone: bf16 sessions must agree bit for bit."""
     size, batch = 256, 2
     sd = api["sd"](phi, 5)
     x = torch.from_numpy(seeded_input((batch, 3, size, size), 23)).cuda()
