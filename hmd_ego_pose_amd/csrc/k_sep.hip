@@ -194,6 +194,8 @@ __global__ __launch_bounds__(SEP_THREADS_OF(MODE, BF16), MODE == 1 ? SEP_M1_WAVE
   // (thread -> (position, channel group): an exact split by CG through a float reciprocal - with the power-of-two split a 160-channel
   //  node used 20 of every 32 lanes: four sweeps over its 100 halo positions instead of two)
   //  (single nodes only: in the multi-segment and chain instantiations the extra live values spilled)
+  //  (measured and left out: two halo items in flight per lane for the two-source top-down nodes - one global round trip instead of
+  //   two at widths above 64 - changed no launch by more than 0.5 us: sixteen waves per CU already overlap the sweeps)
   constexpr bool EXACT = MODE == 0;
   const float cg_rinv = __builtin_amdgcn_rcpf((float)CG);
   const int t_pos = EXACT ? udiv_f((int)threadIdx.x, CG, cg_rinv) : (int)(threadIdx.x >> cgsh);
