@@ -29,6 +29,18 @@
 #include "hep_dev.h"
 #include "hep_internal.h"
 
+// profiling build (make trace): per-wave s_memrealtime stamps at the phase boundaries of the single-node launches on maps of side
+// g_sep_trace_hw, read back with hep_dbg_sep_trace() (tools/trace_sep.py); compiled out of the product library
+#ifdef HEP_TOWER_TRACE
+__device__ unsigned long long* g_sep_trace = nullptr;
+__device__ int g_sep_trace_hw = 0;
+#define SSTAMP(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); sstamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define SSTAMP_NOWAIT(i) do { sstamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define SSTAMP(i)
+#define SSTAMP_NOWAIT(i)
+#endif
+
 // Launch modes:
 //   0  one segment, descriptor in the kernel arguments            (BiFPN node on a 16x16 / 32x32 level)
 //   1  many independent segments, tile -> segment table            (a tower layer / the headers of all heads)
@@ -131,6 +143,10 @@ __global__ __launch_bounds__(SEP_THREADS_OF(MODE, BF16), MODE == 1 ? SEP_M1_WAVE
   constexpr int KSTEP = BF16 ? 32 : 16, KLANE = BF16 ? 8 : 4, PAD = BF16 ? 8 : 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   HEP_POISON(smem, a.lds_bytes);
+#ifdef HEP_TOWER_TRACE
+  unsigned long long sstamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  SSTAMP_NOWAIT(0);
+#endif
   // the segment descriptor is never re-read from global memory: single-segment launches (BiFPN
   // nodes) take it from the kernel arguments (scalar loads), multi-segment launches (heads) copy
   // theirs into LDS once
@@ -212,8 +228,10 @@ __global__ __launch_bounds__(SEP_THREADS_OF(MODE, BF16), MODE == 1 ? SEP_M1_WAVE
         V::store(halo, (int64_t)pos * CH + cg * 8, v);
       }
   }
+  SSTAMP(1);                            // gather done (halo stored)
   park();
   __syncthreads();
+  SSTAMP_NOWAIT(2);
   // staged pointwise weights (a.off_wpw): requested here, under the depthwise phase, parked before the MFMA phase
   T* wpw_s = reinterpret_cast<T*>(smem + a.off_wpw);
   constexpr int NWST = WL ? 4 : 1;
@@ -246,6 +264,7 @@ __global__ __launch_bounds__(SEP_THREADS_OF(MODE, BF16), MODE == 1 ? SEP_M1_WAVE
         V::store(atile, (int64_t)p * CH + cg * 8, acc);
       }
   }
+  SSTAMP(3);                            // depthwise done
   if constexpr (WL) {
     const float cg_inv = __builtin_amdgcn_rcpf((float)CG);
 #pragma unroll
@@ -255,6 +274,7 @@ __global__ __launch_bounds__(SEP_THREADS_OF(MODE, BF16), MODE == 1 ? SEP_M1_WAVE
     }
   }
   __syncthreads();      // halo is dead from here on: its LDS becomes the output tile
+  SSTAMP_NOWAIT(4);                     // staged weights parked, barrier passed
 
   // ---- phase 3: pointwise conv, D[n, pixel] = W[n,:] . tile[pixel,:] -> LDS output tile ----
   const int Nc = sg.N;                                    // columns of this segment
@@ -332,7 +352,9 @@ __global__ __launch_bounds__(SEP_THREADS_OF(MODE, BF16), MODE == 1 ? SEP_M1_WAVE
       }
     }
   }
+  SSTAMP(5);                            // MFMA pairs done
   __syncthreads();
+  SSTAMP_NOWAIT(6);
 
   // ---- phase 4: coalesced copy-out ----
   if (sg.out_f32) {
@@ -368,8 +390,32 @@ __global__ __launch_bounds__(SEP_THREADS_OF(MODE, BF16), MODE == 1 ? SEP_M1_WAVE
   // chain mode: this node's stores must have landed (and every LDS reader be done) before the next
   // node of the chain gathers them - same workgroup, same CU, so a barrier after vmcnt(0) suffices
   if (MODE == 2) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
+#ifdef HEP_TOWER_TRACE
+  if (MODE == 0) {
+    SSTAMP(7);                          // stores acknowledged
+    if (g_sep_trace && (threadIdx.x & 63) == 0 && sg.h == g_sep_trace_hw) {
+      unsigned long long* o = g_sep_trace + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * SEP_WAVES + (threadIdx.x >> 6)) * 8;
+      for (int i = 0; i < 8; i++) o[i] = sstamps[i];
+    }
+  }
+#endif
   }   // chain loop
 }
+
+#ifdef HEP_TOWER_TRACE
+// profiling build: stamps of the LAST single-node launch on a map of side `hw`, [workgroups * waves][8]; hw = 0 turns the stamps off
+extern "C" int hep_dbg_sep_trace(unsigned long long* host, int max_waves, int hw) {
+  static unsigned long long* buf = nullptr;
+  const size_t cap = (size_t)1 << 20;
+  if (!buf) { if (hipMalloc((void**)&buf, cap * 8) != hipSuccess) return -1; }
+  if (!host) hipMemset(buf, 0, cap * 8);
+  unsigned long long* p = hw ? buf : nullptr;
+  hipMemcpyToSymbol(HIP_SYMBOL(g_sep_trace), &p, sizeof p);
+  hipMemcpyToSymbol(HIP_SYMBOL(g_sep_trace_hw), &hw, sizeof hw);
+  if (host) { hipDeviceSynchronize(); hipMemcpy(host, buf, (size_t)max_waves * 64, hipMemcpyDeviceToHost); }
+  return (int)(cap / 8);
+}
+#endif
 
 void sep_lds_layout(int C, int bf16, int ts, int max_cols_f32, int max_cols_map, SepArgs* a, int stage_w) {
   const size_t es = bf16 ? 2 : 4, pad = bf16 ? 8 : 4;
