@@ -4,9 +4,10 @@ from hmd_ego_pose_amd import _capi
 _capi.LIB_PATH = os.path.join(os.path.dirname(_capi.LIB_PATH), "libhep_trace.so")     # make -C hmd_ego_pose_amd/csrc trace
 from hmd_ego_pose_amd.model import Session
 from hmd_ego_pose_amd.weights import seeded_state_dict
-B = 16
-s = Session(seeded_state_dict(0, 0), 0, 256, B, "bf16")
-x = torch.randn(B, 3, 256, 256, device="cuda")
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+phi = int(sys.argv[2]) if len(sys.argv) > 2 else 0; size = int(sys.argv[3]) if len(sys.argv) > 3 else 256
+s = Session(seeded_state_dict(phi, 0), phi, size, B, "bf16")
+x = torch.randn(B, 3, size, size, device="cuda")
 for _ in range(3): s.forward(x, want_features=False)
 torch.cuda.synchronize()
 l = _capi.lib()
