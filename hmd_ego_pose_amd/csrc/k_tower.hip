@@ -693,24 +693,6 @@ int tower_supports(int C) {
 
 int tower_map_tiles(int C) { return (((C + 15) / 16) + 1) & ~1; }      // n-tiles of a map layer (even)
 
-template <bool BF16, int CW, bool HDR>
-static void launch_one(const SepArgs& a, dim3 grid, hipStream_t s, int ipb) {
-  typedef TowerCfg<BF16, CW, HDR> Cfg;
-  hipLaunchKernelGGL((tower_kernel<BF16, CW, HDR>), grid, dim3(Cfg::NW * 64), Cfg::LDS, s, a.segs, a.tile_seg, a.B, ipb);
-}
-
-template <int CW>
-static void launch_w(const SepArgs& a, dim3 grid, hipStream_t s, int ipb) {
-  const bool hdr = a.direct == 2;
-  if (a.coop) {
-    if (a.bf16) { if (hdr) launch_coop<true, CW, true>(a, grid, s, ipb); else launch_coop<true, CW, false>(a, grid, s, ipb); }
-    else { if (hdr) launch_coop<false, CW, true>(a, grid, s, ipb); else launch_coop<false, CW, false>(a, grid, s, ipb); }
-    return;
-  }
-  if (a.bf16) { if (hdr) launch_one<true, CW, true>(a, grid, s, ipb); else launch_one<true, CW, false>(a, grid, s, ipb); }
-  else { if (hdr) launch_one<false, CW, true>(a, grid, s, ipb); else launch_one<false, CW, false>(a, grid, s, ipb); }
-}
-
 // widths / dtypes the cooperative form is instantiated for
 template <bool BF16, int CW> struct CoopBuilt { static constexpr bool value = BF16 ? (CW >= 160 || CW == 64) : CW == 64; };
 int tower_coop_supported(int C, int bf16) {
@@ -733,6 +715,24 @@ static int prepare_coop() {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(tower_coop_kernel<BF16, CW, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024) != hipSuccess) return -1;
   }
   return 0;
+}
+
+template <bool BF16, int CW, bool HDR>
+static void launch_one(const SepArgs& a, dim3 grid, hipStream_t s, int ipb) {
+  typedef TowerCfg<BF16, CW, HDR> Cfg;
+  hipLaunchKernelGGL((tower_kernel<BF16, CW, HDR>), grid, dim3(Cfg::NW * 64), Cfg::LDS, s, a.segs, a.tile_seg, a.B, ipb);
+}
+
+template <int CW>
+static void launch_w(const SepArgs& a, dim3 grid, hipStream_t s, int ipb) {
+  const bool hdr = a.direct == 2;
+  if (a.coop) {
+    if (a.bf16) { if (hdr) launch_coop<true, CW, true>(a, grid, s, ipb); else launch_coop<true, CW, false>(a, grid, s, ipb); }
+    else { if (hdr) launch_coop<false, CW, true>(a, grid, s, ipb); else launch_coop<false, CW, false>(a, grid, s, ipb); }
+    return;
+  }
+  if (a.bf16) { if (hdr) launch_one<true, CW, true>(a, grid, s, ipb); else launch_one<true, CW, false>(a, grid, s, ipb); }
+  else { if (hdr) launch_one<false, CW, true>(a, grid, s, ipb); else launch_one<false, CW, false>(a, grid, s, ipb); }
 }
 
 template <int CW>
