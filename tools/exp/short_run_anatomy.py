@@ -32,6 +32,8 @@ for rep in range(3):
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(D)]; ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(D)]
     base = torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(); t0 = time.perf_counter()
+    if os.environ.get("ANATOMY_SPIN"):          # experiment: how long does the FIRST HIP call of any kind take after the synchronize?
+        q0 = time.perf_counter(); streams[3].query(); print("first stream query after the synchronize: %.0f us" % ((time.perf_counter() - q0) * 1e6))
     base.record(streams[0])
     marks = []; calls.clear()
     for i in range(K):
