@@ -30,7 +30,7 @@ __device__ __forceinline__ float apply_act(float x, int act) {
 // 25.7k -> 26.5k frames/s; ADD against the reference unchanged at 0.003 mm).  The reference's own x * sigmoid(x) rounds twice
 // (efficientnet/utils.py:57-59), so neither form is bit-identical to it; both sit ~1 ulp from the exact quotient.
 __device__ __forceinline__ float rcp_newton(float d) {
-  d = fminf(d, 0x1p126f);                       // e^-x overflowed: keep the step finite (the product is ~1e-37 either way)
+  d = d > 0x1p126f ? 0x1p126f : d;              // e^-x overflowed: keep the step finite (the product is ~1e-37 either way); a NaN stays a NaN (fminf would return the bound)
   const float r = __builtin_amdgcn_rcpf(d);
   return fmaf(fmaf(-d, r, 1.0f), r, r);
 }
@@ -48,7 +48,7 @@ template <bool FAST> __device__ __forceinline__ float sigmoid_t(float x) {
 // VALU pipes are >= 50 % busy with four batches in flight (profiles/r04/d_valu_mix.json), swish is ~a quarter of that.
 template <bool FAST> __device__ __forceinline__ f32x2_t rcp2_t(f32x2_t d) {
   if (FAST) return (f32x2_t){__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
-  d = (f32x2_t){fminf(d[0], 0x1p126f), fminf(d[1], 0x1p126f)};
+  d = (f32x2_t){d[0] > 0x1p126f ? 0x1p126f : d[0], d[1] > 0x1p126f ? 0x1p126f : d[1]};      // NaN-preserving clamp (see rcp_newton)
   const f32x2_t r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
   const f32x2_t e = __builtin_elementwise_fma(-d, r, (f32x2_t){1.0f, 1.0f});
   return __builtin_elementwise_fma(e, r, r);

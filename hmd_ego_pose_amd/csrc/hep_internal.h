@@ -141,6 +141,49 @@ int xbf_prepare(void);
 int xbf_generic_forced(void);                 // HEP_XBF_GENERIC, read when a plan is built
 int xbf_specialised(const XbfArgs&);          // 1: a shape-specialised instantiation exists (names the device function)
 
+// ---- image-resident run of late MBConv blocks (k_late.hip): ONE workgroup per image runs several consecutive stride-1 blocks
+//      of the 8x8 maps back to back - expand 1x1 -> depthwise k x k -> squeeze-excite -> project 1x1 (+ residual) per block
+//      (efficientnet/model.py:69-104) - with block inputs / expanded tiles / squeeze-excite state in LDS and registers and every
+//      weight streamed once per image in MFMA fragment order.  bf16 sessions.  Replaces front + se_finish + project launches. ----
+#define LATE_MAX_BLOCKS 6
+#define LATE_CC 128             // expanded channels per chunk (8 n-tiles)
+#define LATE_THREADS 1024
+struct LateBlock {
+  int Cin, Cexp, N, k, skip;    // 8x8 -> 8x8, stride 1; skip: residual add
+  int nchunks;                  // Cexp / LATE_CC
+  int sq, sqp;                  // squeeze-excite width, padded to a multiple of 8 (<= 64)
+  int ntw, ng;                  // project: n-tiles per wave (2 / 3), n-groups (ng * 2 <= 16 waves: two K halves)
+  float inv_hw;
+  // byte offsets into the launch's weight blob (all 16-byte aligned)
+  uint32_t off_we;              // expand [chunk][n-tile 8][k-step Cin/32][lane 64][8] bf16: one wave instruction = one 1 KB fragment
+  uint32_t off_be;              // [Cexp] f32 expand bias (BN0 shift)
+  uint32_t off_wdw;             // [chunk][k*k][128] f32 depthwise (BN1 folded)
+  uint32_t off_bdw;             // [Cexp] f32
+  uint32_t off_w1;              // squeeze-excite reduce FC [chunk][64 rows (>= sq: zeros)][128] f32
+  uint32_t off_b1;              // [64] f32
+  uint32_t off_w2;              // squeeze-excite expand FC [Cexp][sqp] bf16
+  uint32_t off_b2;              // [Cexp] f32
+  uint32_t off_wp;              // project [n-group][k-step Cexp/32][n-tile ntw][lane 64][8] bf16 (BN2 folded; rows >= N zero)
+  uint32_t off_bp;              // [ng * ntw * 16] f32
+  const void* res;              // [B][64][N] residual = the block's input in global memory (skip blocks)
+  void* out;                    // [B][64][N] block output (always stored: taps, stage tests, the next launch)
+};
+struct LateArgs {
+  const void* in;               // [B][64][Cin of block 0]
+  const unsigned char* blob;
+  void* dscratch;               // [B][Cexp_max / 8][64][8] bf16: depthwise outputs on their way from the chunk loop to the project conv (L2)
+  int dstride;                  // bytes per image of dscratch
+  LateBlock blk[LATE_MAX_BLOCKS];
+  int nblk, B;
+  int off_e, e_stride, off_wdw, wdw_stride, off_bias, off_csum, off_x, off_scale, off_hid;   // LDS layout (late_layout): two buffers each of expanded tiles / depthwise weights / biases / channel sums
+  int lds_bytes;
+  unsigned long long* trace;    // profiling builds (-DHEP_LATE_TRACE)
+};
+int late_layout(LateArgs* a);      // fills the LDS offsets from the blocks' shapes; returns lds_bytes, 0 when the run does not fit
+int late_block_supported(int Cin, int Cexp, int N, int k, int stride, int H, int W, int sq);
+int late_prepare(void);
+void launch_late(const LateArgs&, hipStream_t);
+
 // ---- 3x3 s2 max-pool, TF-SAME with ZERO padding (utils_extra.py:72-86) ----
 struct PoolArgs { const void* in; void* out; int B, H, W, C, Ho, Wo, pad_t, pad_l, bf16; };
 

@@ -231,7 +231,8 @@ enum { F_STEM_W, F_STEM_B, F_STEM_OUT, F_PW_A, F_PW_W, F_PW_B, F_PW_RES, F_PW_OU
        F_DW_OUT, F_DW_PART, F_DW_WR, F_MBF_IN, F_MBF_WE, F_MBF_BE, F_MBF_WDW, F_MBF_BDW, F_MBF_OUT, F_MBF_PART, F_MBF_WR, F_MBF_WESCALE, F_PW_WSCALE, F_PW_SESCALE, F_SE_HPART, F_SE_SCALE, F_SE_BR, F_SE_WE, F_SE_BE, F_PW_HPART, F_PW_SEBR, F_PW_SEWE, F_PW_SEBE, F_POOL_IN, F_POOL_OUT, F_PWG_A, F_PWG_W, F_PWG_B, F_PWG_OUT,
        F_SEG_SRC, F_SEG_WDW, F_SEG_WPW, F_SEG_BIAS, F_SEG_OUT, F_CH_EXT_SRC, F_CH_EXT_STORE, F_CH_NODE_OUT, F_CH_WBLOB,
        F_SBF_WS, F_SBF_BS, F_SBF_WDW, F_SBF_BDW, F_SBF_STEM, F_SBF_OUT, F_SBF_PART, F_SBF_WR,
-       F_XBF_IN, F_XBF_HPART, F_XBF_SEBR, F_XBF_SEWE, F_XBF_SEBE, F_XBF_BLOB, F_XBF_RES, F_XBF_MID, F_XBF_OUT, F_XBF_PART, F_XBF_WR };
+       F_XBF_IN, F_XBF_HPART, F_XBF_SEBR, F_XBF_SEWE, F_XBF_SEBE, F_XBF_BLOB, F_XBF_RES, F_XBF_MID, F_XBF_OUT, F_XBF_PART, F_XBF_WR,
+       F_LATE_IN, F_LATE_BLOB, F_LATE_DS, F_LATE_RES, F_LATE_OUT };
 
 struct Planner {
   Session* s; const Pack& pk; std::string* err; WBuilder wb; bool ok = true;
@@ -258,7 +259,7 @@ struct Planner {
   }
   int new_op(OpKind k, const std::string& name) {
     Op o; memset(&o.stem, 0, sizeof o.stem); memset(&o.pw, 0, sizeof o.pw); memset(&o.dw, 0, sizeof o.dw);
-    memset(&o.pool, 0, sizeof o.pool); memset(&o.sep, 0, sizeof o.sep); memset(&o.mbf, 0, sizeof o.mbf); memset(&o.pwg, 0, sizeof o.pwg); memset(&o.chain, 0, sizeof o.chain); memset(&o.se, 0, sizeof o.se); memset(&o.xbf, 0, sizeof o.xbf); memset(&o.sbf, 0, sizeof o.sbf);
+    memset(&o.pool, 0, sizeof o.pool); memset(&o.sep, 0, sizeof o.sep); memset(&o.mbf, 0, sizeof o.mbf); memset(&o.pwg, 0, sizeof o.pwg); memset(&o.chain, 0, sizeof o.chain); memset(&o.se, 0, sizeof o.se); memset(&o.xbf, 0, sizeof o.xbf); memset(&o.sbf, 0, sizeof o.sbf); memset(&o.late, 0, sizeof o.late);
     o.kind = k; o.name = name;
     s->ops.push_back(o);
     return (int)s->ops.size() - 1;
@@ -735,6 +736,119 @@ struct Planner {
     return defer.out_t;
   }
 
+  // ---- image-resident run of late blocks (k_late.hip): blocks i0 .. i1 as ONE launch, one workgroup per image ----
+  // how many blocks starting at i0 (input map H x W, bf16 sessions) the late kernel can take: 0 = none
+  int late_run(const std::vector<MBConv>& blocks, int i0, int H, int W) const {
+    // HEP_LATE: 0 = launch by launch (front / squeeze-excite / project per block), 1 = the image-resident kernel
+    const char* e = getenv("HEP_LATE");
+    if (!(e ? atoi(e) != 0 : late_default()) || s->dtype != 1) return 0;
+    int n = 0;
+    for (size_t i = i0; i < blocks.size() && n < LATE_MAX_BLOCKS; i++, n++) {
+      const MBConv& b = blocks[i];
+      if (!b.expand || !late_block_supported(b.cin, b.cexp, b.cout, b.k, b.stride, H, W, b.se) || (n > 0 && b.cin != blocks[i - 1].cout)) break;
+    }
+    if (n < 2) return 0;
+    LateArgs probe; memset(&probe, 0, sizeof probe);
+    probe.nblk = n;
+    for (int j = 0; j < n; j++) { const MBConv& b = blocks[i0 + j]; probe.blk[j].Cin = b.cin; probe.blk[j].Cexp = b.cexp; probe.blk[j].N = b.cout; probe.blk[j].k = b.k; }
+    return late_layout(&probe) ? n : 0;
+  }
+  static bool late_default() { return false; }
+  // returns the output tensors of the blocks
+  std::vector<int> add_late(const std::vector<MBConv>& blocks, int i0, int n, int x) {
+    std::vector<int> outs;
+    flush_project();
+    if (!ok) return outs;
+    char nm[64]; snprintf(nm, sizeof nm, "b%d-b%d.blocks", i0, i0 + n - 1);
+    const int op = new_op(OP_LATE, nm);
+    LateArgs la; memset(&la, 0, sizeof la);
+    la.nblk = n;
+    std::vector<unsigned char> blob;
+    auto reserve = [&](size_t bytes) { const size_t off = (blob.size() + 15) & ~(size_t)15; blob.resize(off + bytes, 0); return off; };
+    auto put_bf16 = [&](size_t off, size_t idx, float v) { const uint16_t h = f32_to_bf16(v); memcpy(blob.data() + off + idx * 2, &h, 2); };
+    auto put_f32v = [&](size_t off, size_t idx, float v) { memcpy(blob.data() + off + idx * 4, &v, 4); };
+    int cexp_max = 0;
+    double act = 0, flops = 0;
+    for (int j = 0; j < n; j++) {
+      const MBConv& b = blocks[i0 + j];
+      LateBlock& L = la.blk[j];
+      L.Cin = b.cin; L.Cexp = b.cexp; L.N = b.cout; L.k = b.k; L.skip = b.skip ? 1 : 0; L.nchunks = b.cexp / LATE_CC;
+      L.sq = b.se; L.sqp = (b.se + 7) & ~7; L.inv_hw = 1.0f / 64.0f;
+      cexp_max = std::max(cexp_max, b.cexp);
+    }
+    if (!late_layout(&la)) { *err = "late blocks do not fit LDS"; ok = false; return outs; }      // (fills ntw / ng)
+    for (int j = 0; j < n; j++) {
+      const MBConv& b = blocks[i0 + j];
+      LateBlock& L = la.blk[j];
+      char pb[96]; snprintf(pb, sizeof pb, "backbone_net.model._blocks.%d", i0 + j);
+      const std::string p = pb;
+      const PackTensor *we = get(p + "._expand_conv.conv.weight", {b.cexp, b.cin, 1, 1}), *wd = get(p + "._depthwise_conv.conv.weight", {b.cexp, 1, b.k, b.k}),
+                       *wr = get(p + "._se_reduce.conv.weight", {b.se, b.cexp, 1, 1}), *br = get(p + "._se_reduce.conv.bias", {b.se}),
+                       *w2 = get(p + "._se_expand.conv.weight", {b.cexp, b.se, 1, 1}), *b2 = get(p + "._se_expand.conv.bias", {b.cexp}),
+                       *wp = get(p + "._project_conv.conv.weight", {b.cout, b.cexp, 1, 1});
+      BnFold bn0, bn1, bn2;
+      if (!fold_bn(pk, p + "._bn0", b.cexp, &bn0, err) || !fold_bn(pk, p + "._bn1", b.cexp, &bn1, err) || !fold_bn(pk, p + "._bn2", b.cout, &bn2, err)) ok = false;
+      if (!ok) return outs;
+      const int kse = b.cin / 32, ksp = b.cexp / 32, kk = b.k * b.k, NC = L.nchunks, sqp = L.sqp;
+      // expand weights in MFMA fragment order: [chunk][n-tile][k-step][lane = (r, g)][8]: W[n = c*128 + t*16 + r][k = ks*32 + 8g + e]
+      L.off_we = (uint32_t)reserve((size_t)b.cexp * b.cin * 2);
+      for (int c = 0; c < NC; c++) for (int t = 0; t < 8; t++) for (int ks = 0; ks < kse; ks++) for (int lane = 0; lane < 64; lane++) for (int e = 0; e < 8; e++) {
+        const int nn = c * LATE_CC + t * 16 + (lane & 15), k = ks * 32 + 8 * (lane >> 4) + e;
+        put_bf16(L.off_we, ((size_t)((c * 8 + t) * kse + ks) * 64 + lane) * 8 + e, we->data[(size_t)nn * b.cin + k] * bn0.scale[nn]);
+      }
+      L.off_be = (uint32_t)reserve((size_t)b.cexp * 4);
+      for (int c = 0; c < b.cexp; c++) put_f32v(L.off_be, c, bn0.shift[c]);
+      L.off_wdw = (uint32_t)reserve((size_t)kk * b.cexp * 4);
+      for (int c = 0; c < NC; c++) for (int t = 0; t < kk; t++) for (int i = 0; i < LATE_CC; i++) {
+        const int ch = c * LATE_CC + i;
+        put_f32v(L.off_wdw, ((size_t)c * kk + t) * LATE_CC + i, wd->data[(size_t)ch * kk + t] * bn1.scale[ch]);
+      }
+      L.off_bdw = (uint32_t)reserve((size_t)b.cexp * 4);
+      for (int c = 0; c < b.cexp; c++) put_f32v(L.off_bdw, c, bn1.shift[c]);
+      L.off_w1 = (uint32_t)reserve((size_t)NC * sqp * LATE_CC * 4);
+      for (int c = 0; c < NC; c++) for (int jj = 0; jj < b.se; jj++) for (int i = 0; i < LATE_CC; i++)
+        put_f32v(L.off_w1, ((size_t)c * sqp + jj) * LATE_CC + i, wr->data[(size_t)jj * b.cexp + c * LATE_CC + i]);
+      L.off_b1 = (uint32_t)reserve(64 * 4);
+      for (int jj = 0; jj < b.se; jj++) put_f32v(L.off_b1, jj, br->data[jj]);
+      L.off_w2 = (uint32_t)reserve((size_t)b.cexp * sqp * 2);
+      for (int c = 0; c < b.cexp; c++) for (int jj = 0; jj < b.se; jj++) put_bf16(L.off_w2, (size_t)c * sqp + jj, w2->data[(size_t)c * b.se + jj]);
+      L.off_b2 = (uint32_t)reserve((size_t)b.cexp * 4);
+      for (int c = 0; c < b.cexp; c++) put_f32v(L.off_b2, c, b2->data[c]);
+      // project weights: [n-group][k-step][n-tile of the group][lane][8]: W[n = (ng*ntw + jt)*16 + r][k = ks*32 + 8g + e], rows >= N zero
+      L.off_wp = (uint32_t)reserve((size_t)L.ng * ksp * L.ntw * 1024);
+      for (int ng = 0; ng < L.ng; ng++) for (int ks = 0; ks < ksp; ks++) for (int jt = 0; jt < L.ntw; jt++) for (int lane = 0; lane < 64; lane++) {
+        const int nn = (ng * L.ntw + jt) * 16 + (lane & 15);
+        if (nn >= b.cout) continue;
+        for (int e = 0; e < 8; e++) {
+          const int k = ks * 32 + 8 * (lane >> 4) + e;
+          put_bf16(L.off_wp, ((size_t)((ng * ksp + ks) * L.ntw + jt) * 64 + lane) * 8 + e, wp->data[(size_t)nn * b.cexp + k] * bn2.scale[nn]);
+        }
+      }
+      L.off_bp = (uint32_t)reserve((size_t)L.ng * L.ntw * 16 * 4);
+      for (int c = 0; c < b.cout; c++) put_f32v(L.off_bp, c, bn2.shift[c]);
+      const int out_t = tensor(std::string("block") + std::to_string(i0 + j), 8, 8, b.cout);
+      outs.push_back(out_t);
+      act += 64.0 * b.cout * es() * (b.skip ? 2 : 1);
+      flops += 2.0 * 64 * b.cin * b.cexp + 2.0 * kk * 64 * b.cexp + 2.0 * 64 * b.cexp * b.cout + 4.0 * b.cexp * b.se;
+    }
+    const size_t boff = wb.alloc(blob.size());
+    memcpy(wb.host.data() + boff, blob.data(), blob.size());
+    const int ds_t = tensor(std::string(nm) + ".dw", 1, 1, 64 * cexp_max);
+    la.dstride = 64 * cexp_max * 2;
+    s->ops[op].late = la;
+    wref(op, F_LATE_BLOB, boff);
+    tref(op, F_LATE_IN, x, false); tref(op, F_LATE_DS, ds_t, true);
+    for (int j = 0; j < n; j++) {
+      tref(op, F_LATE_OUT, outs[j], true, j);
+      if (blocks[i0 + j].skip) tref(op, F_LATE_RES, j == 0 ? x : outs[j - 1], false, j);
+    }
+    Op& o = s->ops[op];
+    o.act_bytes_per_image = 64.0 * blocks[i0].cin * es() + act;      // (the depthwise outputs' round trip through L2 is the kernel's own business)
+    o.weight_bytes = (double)blob.size();
+    o.flops_per_image = flops;
+    return outs;
+  }
+
   // ---- fused separable conv launch (1..n segments sharing C) ----
   struct SegSpec {
     int src[3]; int kind[3]; float fw[3]; int nsrc; int pre_act;
@@ -1078,6 +1192,15 @@ int build_session(Session* s, const Pack& pack, std::string* err) {
   int taps[3] = {-1, -1, -1};
   for (int t = 0; t < 3; t++) P.tap_blocks.push_back(A.taps[t]);
   for (size_t i = 0; i < A.blocks.size(); i++) {
+    if (const int nl = P.late_run(A.blocks, (int)i, H, W)) {        // blocks i .. i + nl - 1 as one image-resident launch (k_late.hip)
+      const std::vector<int> outs = P.add_late(A.blocks, (int)i, nl, x);
+      if (!P.ok || (int)outs.size() != nl) return HEP_ERR_PACK;
+      for (int j = 0; j < nl; j++)
+        for (int t = 0; t < 3; t++) if (A.taps[t] == (int)i + j) taps[t] = outs[j];
+      x = outs.back();
+      i += nl - 1;
+      continue;
+    }
     x = P.add_mbconv((int)i, A.blocks[i], x, &H, &W);
     if (!P.ok) return HEP_ERR_PACK;
     for (int t = 0; t < 3; t++) if (A.taps[t] == (int)i) taps[t] = x;
@@ -1293,6 +1416,7 @@ int build_session(Session* s, const Pack& pack, std::string* err) {
   if (tower_prepare() != 0) { *err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for tower_kernel"; return HEP_ERR_DEVICE; }
   if (filter_prepare() != 0) { *err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for filter_kernel"; return HEP_ERR_DEVICE; }
   if (sep_prepare() != 0) { *err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"; return HEP_ERR_DEVICE; }
+  if (late_prepare() != 0) { *err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for late_kernel"; return HEP_ERR_DEVICE; }
   HIPCHK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
   s->weights_bytes = P.wb.host.size();
   HIPCHK(hipMalloc((void**)&s->d_weights, s->weights_bytes));
@@ -1391,6 +1515,11 @@ int build_session(Session* s, const Pack& pack, std::string* err) {
         case F_XBF_OUT: o.xbf.out = ptr; break;
         case F_XBF_PART: o.xbf.hpart_out = (float*)ptr; break;
         case F_XBF_WR: o.xbf.se_wr = (const float*)ptr; break;
+        case F_LATE_IN: o.late.in = ptr; break;
+        case F_LATE_BLOB: o.late.blob = (const unsigned char*)ptr; break;
+        case F_LATE_DS: o.late.dscratch = ptr; break;
+        case F_LATE_RES: o.late.blk[r.seg].res = ptr; break;
+        case F_LATE_OUT: o.late.blk[r.seg].out = ptr; break;
       }
     }
     // segment tables to device

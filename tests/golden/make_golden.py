@@ -91,7 +91,8 @@ def main():
     # ---- 2. network forward: reference module on seeded weights ---------------------------
     cams = np.array([[480, 480, 128, 128, 1000, 1.0],
                      [572.4114, 573.57043, 325.2611, 242.04899, 1000, 0.8]], dtype=np.float32)
-    for (phi, size, batch, seed, kind) in ((0, 256, 2, 0, "normal"), (0, 256, 1, 1, "uniform"), (3, 512, 1, 0, "normal")):
+    from tests._util import CASES, strides_for      # one table of cases / slice strides for this script and the tests
+    for (phi, size, batch, seed, kind) in CASES.values():
         tag = f"phi{phi}_s{size}_b{batch}_seed{seed}"
         model = HMDEgoPose({"iter": 0}, num_classes=1, compound_coef=phi, onnx_export=True, input_sizes=[size] * 9).eval()
         ref_keys = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
@@ -127,16 +128,15 @@ def main():
         for k, v in trace.items():
             named["trace_" + k] = v.permute(0, 2, 3, 1)
         for k, v in named.items():
-            stride = (97 if size == 256 else 397) if not k.startswith("trace_") else (1009 if size == 256 else 8191)
-            info[k], out[k] = digest(v.numpy(), stride)
+            info[k], out[k] = digest(v.numpy(), strides_for(size, k, batch))
         # decode through the reference's own format_bboxes / format_translation
         anchors, t_anchors = create_anchors(size)
         for ci, cam in enumerate(cams):
             camb = torch.from_numpy(np.repeat(cam[None], batch, 0))
             boxes = format_bboxes(x, anchors, reg).numpy()
             trans = format_translation(t_anchors, trn, camb).numpy()
-            info[f"boxes_cam{ci}"], out[f"boxes_cam{ci}"] = digest(boxes, 97 if size == 256 else 397)
-            info[f"translation_cam{ci}"], out[f"translation_cam{ci}"] = digest(trans, 97 if size == 256 else 397)
+            info[f"boxes_cam{ci}"], out[f"boxes_cam{ci}"] = digest(boxes, strides_for(size, "boxes", batch))
+            info[f"translation_cam{ci}"], out[f"translation_cam{ci}"] = digest(trans, strides_for(size, "translation", batch))
         np.savez_compressed(os.path.join(HERE, f"net_{tag}.npz"), **out)
         meta[tag] = info
         print(tag, "done:", {k: round(v["abssum"], 3) for k, v in list(info.items())[:5]})

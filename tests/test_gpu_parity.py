@@ -79,7 +79,7 @@ def test_fp32_forward_matches_oracle_and_reference_golden(api, tag):
     # golden vectors from the real reference
     info, gold = golden_case(tag)
     for k, v in got.items():
-        check_digest(k, v.numpy(), info[k], gold[k], strides_for(size, k), atol=1e-3, rtol=1e-4)
+        check_digest(k, v.numpy(), info[k], gold[k], strides_for(size, k, batch), atol=1e-3, rtol=1e-4)
     s.close()
 
 

@@ -52,10 +52,10 @@ def test_network_forward_matches_reference(tag):
             named[f"trace_{k}"] = v.permute(0, 2, 3, 1)
     assert len(named) >= 10 + len([k for k in info if k.startswith("trace_")])
     for k, v in named.items():
-        check_digest(k, v.numpy(), info[k], gold[k], strides_for(size, k), atol=1e-5, rtol=1e-5)
+        check_digest(k, v.numpy(), info[k], gold[k], strides_for(size, k, batch), atol=1e-5, rtol=1e-5)
     # decode against the reference's own format_bboxes / format_translation
     anchors, t_anchors = D.anchors_for_size(size)
-    st = strides_for(size, "boxes")
+    st = strides_for(size, "boxes", batch)
     for ci, cam in enumerate(CAMS):
         boxes = D.decode_boxes(anchors, reg.numpy(), size)
         trans = D.decode_translation(t_anchors, trn.numpy(), np.repeat(cam[None], batch, 0))
