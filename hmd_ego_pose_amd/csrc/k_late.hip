@@ -44,8 +44,14 @@ constexpr int LATE_NDW = 8;                     // waves 0..7 depthwise, 8..15 e
 constexpr int LATE_MM_LANES = LATE_THREADS - LATE_NDW * 64;
 }
 
+// Optional per-wave timeline (make trace: -DHEP_LATE_TRACE): s_memrealtime (100 MHz) stamps, 64 slots per (workgroup, wave, block),
+// read back with hep_dbg_late_trace() (tools/trace_late.py) - profiling builds only.
+//   0 block start, 1 first chunk barrier, 2 chunk loop done, 3 scale ready, 4 As parked, 5 block done, 6 K loop done, 7 partials parked
+//   8 + c: barrier behind chunk c;  32..: inside chunk 1 - mm: 32 top, 33 expand done, 34 squeeze-excite partial done, 35 weights parked;
+//   dw: 40 top, 41 taps done, 42 outputs stored, 43 channel sums done
 #ifdef HEP_LATE_TRACE
-#define LSTAMP(i) do { if (lane == 0 && a.trace) a.trace[((size_t)blockIdx.x * 16 + wave) * 64 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+__device__ unsigned long long* g_late_trace = nullptr;
+#define LSTAMP(i) do { if (g_late_trace && lane == 0) g_late_trace[(((size_t)blockIdx.x * 16 + wave) * LATE_MAX_BLOCKS + bi) * 64 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define LSTAMP(i)
 #endif
@@ -56,7 +62,7 @@ __device__ __forceinline__ u32x4 late_ldg(const unsigned char* p) { return *rein
 template <int KS>
 __device__ __forceinline__ void late_zero_halo(unsigned char* smem, const LateArgs& a) {
   constexpr int PW = KS + 7, PAD = (KS - 1) / 2, VPP = LATE_EP * 2 / 16, PER = PW * PW * VPP;
-  for (int u = threadIdx.x; u < 2 * PER; u += LATE_THREADS) {
+  for (int u = threadIdx.x; u < 2 * PER; u += LATE_NDW * 64) {      // (called by the depthwise waves: threads 0 .. 511)
     const int buf = u >= PER ? 1 : 0, rem = u - buf * PER, p = rem / VPP, v = rem - p * VPP;
     const int ty = p / PW, tx = p - ty * PW;
     if (ty < PAD || ty >= PAD + 8 || tx < PAD || tx >= PAD + 8)
@@ -66,7 +72,7 @@ __device__ __forceinline__ void late_zero_halo(unsigned char* smem, const LateAr
 
 // ---- project conv of one block: As[64][Cexp] (LDS, scaled) x Wp -> + bias (+ residual) -> global + next input tile ----
 template <int NTW>
-__device__ __forceinline__ void late_project(const LateArgs& a, const LateBlock& L, unsigned char* smem, int b, bool last_block) {
+__device__ __forceinline__ void late_project(const LateArgs& a, const LateBlock& L, unsigned char* smem, int b, bool last_block, int bi) {
   int tid_ = threadIdx.x;
   asm volatile("" : "+v"(tid_));       // (opaque per call: lane-derived addresses are not hoisted to kernel entry and spilled there)
   const int lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6), r = lane & 15, g = lane >> 4;
@@ -79,6 +85,22 @@ __device__ __forceinline__ void late_project(const LateArgs& a, const LateBlock&
   for (int j = 0; j < NTW; j++)
 #pragma unroll
     for (int mt = 0; mt < 4; mt++) acc[j][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // residual and bias of the lanes that finish the tile (K half 0): requested before the K loop where the registers allow it
+  // (two n-tiles per wave), behind it otherwise - a round trip to L2 in front of the partial-sum barrier cost 2 us per block
+  u32x2 resv[NTW][4]; f32x4 biasv[NTW];
+  auto load_tail = [&]() {
+    if (active && kq == 0) {
+#pragma unroll
+      for (int j = 0; j < NTW; j++) {
+        const int n = min((ng * NTW + j) * 16 + 4 * g, L.N - 4);
+        biasv[j] = *reinterpret_cast<const f32x4*>(a.blob + L.off_bp + (size_t)((ng * NTW + j) * 16 + 4 * g) * 4);
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++)
+          resv[j][mt] = L.skip ? *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(L.res) + ((size_t)b * 64 + mt * 16 + r) * L.N + n) : (u32x2){0u, 0u};
+      }
+    }
+  };
+  if constexpr (NTW <= 2) load_tail();
   if (active) {
     constexpr int R = 3;                                     // k-steps of weight fragments in flight
     const unsigned char* wp = a.blob + L.off_wp + ((size_t)(ng * KSP + kq * KSH) * NTW * 64 + lane) * 16;
@@ -107,18 +129,8 @@ __device__ __forceinline__ void late_project(const LateArgs& a, const LateBlock&
       }
     }
   }
-  // residual and bias of the lanes that finish the tile (K half 0): requested here, they land under the two barriers
-  u32x2 resv[NTW][4]; f32x4 biasv[NTW];
-  if (active && kq == 0) {
-#pragma unroll
-    for (int j = 0; j < NTW; j++) {
-      const int n = min((ng * NTW + j) * 16 + 4 * g, L.N - 4);
-      biasv[j] = *reinterpret_cast<const f32x4*>(a.blob + L.off_bp + (size_t)((ng * NTW + j) * 16 + 4 * g) * 4);
-#pragma unroll
-      for (int mt = 0; mt < 4; mt++)
-        resv[j][mt] = L.skip ? *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(L.res) + ((size_t)b * 64 + mt * 16 + r) * L.N + n) : (u32x2){0u, 0u};
-    }
-  }
+  LSTAMP(6);
+  if constexpr (NTW > 2) load_tail();
   __syncthreads();                                           // As is dead: its space takes the K-half partial sums
   f32x4* part = reinterpret_cast<f32x4*>(smem);
   if (active && kq == 1) {
@@ -128,6 +140,7 @@ __device__ __forceinline__ void late_project(const LateArgs& a, const LateBlock&
       for (int mt = 0; mt < 4; mt++) part[((ng * NTW + j) * 4 + mt) * 64 + lane] = acc[j][mt];
   }
   __syncthreads();
+  LSTAMP(7);
   if (active && kq == 0) {
     bf16_t* Xn = reinterpret_cast<bf16_t*>(smem + a.off_x);
     const int XPn = L.N + 8;
@@ -158,7 +171,7 @@ __device__ __forceinline__ void late_project(const LateArgs& a, const LateBlock&
 
 // ---- one block ----
 template <int KS, int KSE>
-__device__ __forceinline__ void late_block(const LateArgs& a, const LateBlock& L, unsigned char* smem, int b, bool last_block) {
+__device__ __forceinline__ void late_block(const LateArgs& a, const LateBlock& L, unsigned char* smem, int b, bool last_block, int bi) {
   constexpr int PW = KS + 7, PAD = (KS - 1) / 2, KK = KS * KS, KH = (KS + 1) / 2, NXP = KS + 3;
   int tid = threadIdx.x;
   asm volatile("" : "+v"(tid));        // (opaque per block: the compiler hoisted the lane-derived addresses of every instantiation to kernel entry and spilled them)
@@ -169,7 +182,7 @@ __device__ __forceinline__ void late_block(const LateArgs& a, const LateBlock& L
   const bf16_t* Xs = reinterpret_cast<const bf16_t*>(smem + a.off_x);
   const unsigned char* blob = a.blob;
   unsigned char* dimg = reinterpret_cast<unsigned char*>(a.dscratch) + (size_t)b * a.dstride;
-  float hacc = 0.f;                                             // mm lanes: reduce-FC partial of hidden unit sj over channel slice spart
+  float hacc = 0.f, b1v = 0.f;                                  // mm lanes: reduce-FC partial of hidden unit sj over channel slice spart; its bias
   const int sj = ml >> 3, spart = ml & 7;
   const bool se_lane = mm && sj < sqp;
 
@@ -235,13 +248,15 @@ __device__ __forceinline__ void late_block(const LateArgs& a, const LateBlock& L
     const float* bd = reinterpret_cast<const float*>(smem + a.off_bias + (c & 1) * 512);
     const int yx = lane & 15, cgw = (lane >> 4) & 1, rg = lane >> 5;
     const int cg = wave * 2 + cgw, y = yx >> 1, xh = yx & 1;
-    float acc[4][8];
+    f32x2_t acc[4][4];                                         // [pixel of the strip][channel pair]: every multiply-add is a v_pk_fma_f32
     {
       const f32x4 b0 = *reinterpret_cast<const f32x4*>(bd + cg * 8), b1 = *reinterpret_cast<const f32x4*>(bd + cg * 8 + 4);
+      const f32x2_t z = {0.f, 0.f};
 #pragma unroll
-      for (int px = 0; px < 4; px++)
-#pragma unroll
-        for (int ch = 0; ch < 4; ch++) { acc[px][ch] = rg ? 0.f : b0[ch]; acc[px][4 + ch] = rg ? 0.f : b1[ch]; }
+      for (int px = 0; px < 4; px++) {
+        acc[px][0] = rg ? z : (f32x2_t){b0[0], b0[1]}; acc[px][1] = rg ? z : (f32x2_t){b0[2], b0[3]};
+        acc[px][2] = rg ? z : (f32x2_t){b1[0], b1[1]}; acc[px][3] = rg ? z : (f32x2_t){b1[2], b1[3]};
+      }
     }
     const int ky0 = rg ? KH : 0, nrows = rg ? KS - KH : KH;
 #pragma unroll 1
@@ -249,54 +264,64 @@ __device__ __forceinline__ void late_block(const LateArgs& a, const LateBlock& L
       if (it < nrows) {
         const int ky = ky0 + it;
         const bf16_t* erow = E + ((y + ky) * PW + xh * 4) * LATE_EP + cg * 8;
-        // the row's KS weight vectors stay in registers; the KS + 3 input positions are unpacked one at a time and feed the (up to
-        // four) pixels whose window holds them - per accumulator the taps still arrive in kx order (k_mbf.hip's order)
-        f32x4 w0[KS], w1[KS];
+        // the row's KS weight vectors stay in registers; the KS + 3 input positions are unpacked one at a time (a bf16 pair word IS
+        // a channel pair: shift / mask -> the two halves of a packed operand) and feed the (up to four) pixels whose window holds
+        // them - per accumulator the taps still arrive in kx order (k_mbf.hip's order)
+        f32x2_t w[KS][4];
 #pragma unroll
         for (int kx = 0; kx < KS; kx++) {
           const f32x4* wp = reinterpret_cast<const f32x4*>(wd + (ky * KS + kx) * LATE_CC + cg * 8);
-          w0[kx] = wp[0]; w1[kx] = wp[1];
+          const f32x4 w0 = wp[0], w1 = wp[1];
+          w[kx][0] = (f32x2_t){w0[0], w0[1]}; w[kx][1] = (f32x2_t){w0[2], w0[3]}; w[kx][2] = (f32x2_t){w1[0], w1[1]}; w[kx][3] = (f32x2_t){w1[2], w1[3]};
         }
 #pragma unroll
         for (int j = 0; j < NXP; j++) {
-          float ev[8];
-          Vec8<true>::load(erow, (int64_t)j * LATE_EP, ev);
+          const u32x4 raw = *reinterpret_cast<const u32x4*>(erow + j * LATE_EP);
+          f32x2_t ev[4];
+#pragma unroll
+          for (int q = 0; q < 4; q++) ev[q] = (f32x2_t){__uint_as_float(raw[q] << 16), __uint_as_float(raw[q] & 0xffff0000u)};
 #pragma unroll
           for (int px = 0; px < 4; px++) {
             const int kx = j - px;
             if (kx >= 0 && kx < KS) {
 #pragma unroll
-              for (int ch = 0; ch < 4; ch++) {
-                acc[px][ch] = fmaf(ev[ch], w0[kx][ch], acc[px][ch]);
-                acc[px][4 + ch] = fmaf(ev[4 + ch], w1[kx][ch], acc[px][4 + ch]);
-              }
+              for (int q = 0; q < 4; q++) acc[px][q] = __builtin_elementwise_fma(ev[q], w[kx][q], acc[px][q]);
             }
           }
         }
       }
     }
+    if (c == 1) LSTAMP(41);
     // the two tap-row halves meet: lanes 0-31 finish pixels 0,1 of the strip, lanes 32-63 pixels 2,3 (first + second)
     float cs8[8];
 #pragma unroll
     for (int p = 0; p < 2; p++) {
       float v[8];
 #pragma unroll
-      for (int ch = 0; ch < 8; ch++) {
-        const u32x2 sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[p][ch]), __float_as_uint(acc[2 + p][ch]), false, false);
-        v[ch] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
-      }
+      for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          const u32x2 sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[p][q][h]), __float_as_uint(acc[2 + p][q][h]), false, false);
+          v[2 * q + h] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+        }
       swish_n<true, 8>(v);
 #pragma unroll
       for (int ch = 0; ch < 8; ch++) cs8[ch] = p ? cs8[ch] + v[ch] : v[ch];
       const int px = y * 8 + xh * 4 + rg * 2 + p;
       Vec8<true>::store(dimg, ((int64_t)(c * 16 + cg) * 64 + px) * 8, v);
     }
-    // channel sums over the 32 lanes of this channel group (16 strips x 2 halves): fixed butterfly
+    if (c == 1) LSTAMP(42);
+    // channel sums over the 32 lanes of this channel group (16 strips x 2 halves): DPP adds inside the 16-lane row (quad, quad pair,
+    // half row, row), then the two halves of the wave (fixed order, no LDS round trips: five ds_bpermute per value cost 1 us per chunk)
 #pragma unroll
     for (int ch = 0; ch < 8; ch++) {
       float s = cs8[ch];
-      s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64); s += __shfl_xor(s, 32, 64);
-      cs8[ch] = s;
+      s += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(s), 0xB1, 0xf, 0xf, false));     // quad_perm [1,0,3,2]
+      s += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(s), 0x4E, 0xf, 0xf, false));     // quad_perm [2,3,0,1]
+      s += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(s), 0x141, 0xf, 0xf, false));    // row_half_mirror
+      s += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(s), 0x140, 0xf, 0xf, false));    // row_mirror
+      const u32x2 sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+      cs8[ch] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
     }
     if (yx == 0 && rg == 0) {
       f32x4* d = reinterpret_cast<f32x4*>(smem + a.off_csum + (c & 1) * 512 + cg * 32);
@@ -306,34 +331,52 @@ __device__ __forceinline__ void late_block(const LateArgs& a, const LateBlock& L
 
   // ---- chunk loop: the two roles run their own loops (one barrier per chunk each - a role's registers are not live in the other's code) ----
   LSTAMP(0);
-  late_zero_halo<KS>(smem, a);
   if (mm) {
-    load_w(0); load_dw(0); expand(0); park_dw(0); if (NC > 1) load_w(1);
+    // Every load of an iteration is consumed in the NEXT one (the compiler waits with vmcnt(0) behind the loop edge: a load
+    // requested at the top of an iteration and the fragments requested a chunk ago are then waited for together - measured: the
+    // expand phase took 4.5 us of a 4.9 us chunk that way and the depthwise waves idled 2 us per chunk at the barrier)
+    load_w(0); load_dw(0);
+    expand(0); park_dw(0);
+    if (NC > 1) { load_w(1); load_dw(1); }
     __syncthreads();
+    LSTAMP(1);
     for (int c = 0; c < NC; c++) {
-      if (c + 1 < NC) load_dw(c + 1);
-      if (c >= 1) load_w1(c - 1);
-      if (c + 1 < NC) { expand(c + 1); if (c + 2 < NC) load_w(c + 2); }
-      if (c >= 1) se_partial(c - 1);
+      if (c == 1) LSTAMP(32);
+      if (c + 1 < NC) expand(c + 1);
+      if (c == 1) LSTAMP(33);
+      if (c >= 1) se_partial(c - 1);                             // (its reduce-FC slice was requested in the previous iteration)
+      if (c == 1) LSTAMP(34);
       if (c + 1 < NC) park_dw(c + 1);
+      if (c + 2 < NC) { load_w(c + 2); load_dw(c + 2); }
+      load_w1(c);
+      if (c == NC - 1) b1v = *reinterpret_cast<const float*>(blob + L.off_b1 + (size_t)(se_lane ? sj : 0) * 4);
+      if (c == 1) LSTAMP(35);
       __syncthreads();
+      LSTAMP(8 + c);
     }
   } else {
+    late_zero_halo<KS>(smem, a);                                // (the depthwise waves: idle until the first chunk is expanded)
     __syncthreads();
+    LSTAMP(1);
     for (int c = 0; c < NC; c++) {
+      if (c == 1) LSTAMP(40);
       dwconv(c);
+      if (c == 1) LSTAMP(43);
       __syncthreads();
+      LSTAMP(8 + c);
     }
   }
   LSTAMP(2);
 
-  // ---- squeeze-excite: hidden vector, scale ----
+  // ---- squeeze-excite: hidden vector, scale; As = depthwise output x scale ----
   float* hid_s = reinterpret_cast<float*>(smem + a.off_hid);
   float* scale_s = reinterpret_cast<float*>(smem + a.off_scale);
-  // this thread's rows of the expand FC (two of Cexp <= 2048) do not depend on the hidden vector: requested first
+  // Nothing below depends on the hidden vector until the expand FC: this thread's rows of that FC (two of Cexp <= 2048) and its
+  // share of the depthwise outputs (Cexp / 128 16-byte units, back from L2) are requested first and land under the two barriers
   constexpr int W2V = 6;                                       // 16-byte vectors per row (sqp <= 48)
+  constexpr int NDU = 9;                                       // depthwise-output units per thread (Cexp <= 1152)
   const int nv2 = sqp >> 3;
-  u32x4 w2a[W2V], w2b[W2V];
+  u32x4 w2a[W2V], w2b[W2V], dreg[NDU];
   const int k0 = tid, k1 = tid + LATE_THREADS;
   {
     const unsigned char* p0 = blob + L.off_w2 + (size_t)min(k0, L.Cexp - 1) * sqp * 2;
@@ -343,13 +386,15 @@ __device__ __forceinline__ void late_block(const LateArgs& a, const LateBlock& L
   }
   const float b2a = *reinterpret_cast<const float*>(blob + L.off_b2 + (size_t)min(k0, L.Cexp - 1) * 4);
   const float b2b = *reinterpret_cast<const float*>(blob + L.off_b2 + (size_t)min(k1, L.Cexp - 1) * 4);
+#pragma unroll
+  for (int i = 0; i < NDU; i++) dreg[i] = late_ldg(dimg + (size_t)(tid + LATE_THREADS * min(i, NC - 1)) * 16);
   if (mm) {
-    const float b1 = *reinterpret_cast<const float*>(blob + L.off_b1 + (size_t)(se_lane ? sj : 0) * 4);
-    load_w1(NC - 1);
-    se_partial(NC - 1);
+    se_partial(NC - 1);                                        // (its reduce-FC slice and bias were requested inside the last chunk)
     float s = hacc;
-    s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
-    if (se_lane && spart == 0) hid_s[sj] = sj < L.sq ? swishf(fmaf(s, L.inv_hw, b1)) : 0.f;
+    s += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(s), 0xB1, 0xf, 0xf, false));      // the eight channel slices of a hidden unit: lanes 8 j .. 8 j + 7
+    s += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(s), 0x4E, 0xf, 0xf, false));
+    s += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(s), 0x141, 0xf, 0xf, false));
+    if (se_lane && spart == 0) hid_s[sj] = sj < L.sq ? swishf(fmaf(s, L.inv_hw, b1v)) : 0.f;
   }
   __syncthreads();
   {
@@ -372,34 +417,27 @@ __device__ __forceinline__ void late_block(const LateArgs& a, const LateBlock& L
   }
   __syncthreads();
   LSTAMP(3);
-
-  // ---- As = depthwise output x scale, bf16, [64][Cexp + 8] over the dead chunk buffers ----
   {
     bf16_t* As = reinterpret_cast<bf16_t*>(smem);
     const int AP = L.Cexp + 8, px = tid & 63;
-    for (int i0 = 0; i0 < NC; i0 += 3) {
-      u32x4 d[3];
 #pragma unroll
-      for (int i = 0; i < 3; i++) d[i] = late_ldg(dimg + (size_t)(tid + LATE_THREADS * min(i0 + i, NC - 1)) * 16);
+    for (int i = 0; i < NDU; i++) {
+      if (i < NC) {
+        const int cgi = wave + 16 * i;
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(scale_s + cgi * 8), s1 = *reinterpret_cast<const f32x4*>(scale_s + cgi * 8 + 4);
+        const float sc[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+        u32x4 raw = dreg[i];
 #pragma unroll
-      for (int i = 0; i < 3; i++) {
-        if (i0 + i < NC) {
-          const int cgi = wave + 16 * (i0 + i);
-          const f32x4 s0 = *reinterpret_cast<const f32x4*>(scale_s + cgi * 8), s1 = *reinterpret_cast<const f32x4*>(scale_s + cgi * 8 + 4);
-          const float s[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
-          u32x4 raw = d[i];
-#pragma unroll
-          for (int q = 0; q < 4; q++)
-            raw[q] = pack_bf16x2(__uint_as_float(raw[q] << 16) * s[2 * q], __uint_as_float(raw[q] & 0xffff0000u) * s[2 * q + 1]);
-          *reinterpret_cast<u32x4*>(As + (int64_t)px * AP + cgi * 8) = raw;
-        }
+        for (int q = 0; q < 4; q++)
+          raw[q] = pack_bf16x2(__uint_as_float(raw[q] << 16) * sc[2 * q], __uint_as_float(raw[q] & 0xffff0000u) * sc[2 * q + 1]);
+        *reinterpret_cast<u32x4*>(As + (int64_t)px * AP + cgi * 8) = raw;
       }
     }
   }
   __syncthreads();
   LSTAMP(4);
-  if (L.ntw == 2) late_project<2>(a, L, smem, b, last_block);
-  else late_project<3>(a, L, smem, b, last_block);
+  if (L.ntw == 2) late_project<2>(a, L, smem, b, last_block, bi);
+  else late_project<3>(a, L, smem, b, last_block, bi);
   LSTAMP(5);
 }
 
@@ -424,16 +462,29 @@ __global__ __launch_bounds__(LATE_THREADS) void late_kernel(LateArgs a_by_value)
   for (int i = 0; i < a.nblk; i++) {
     const LateBlock& L = a.blk[i];
     const bool last = i + 1 == a.nblk;
-    if (L.k == 5) late_block<5, 6>(a, L, smem, b, last);
-    else late_block<3, 6>(a, L, smem, b, last);
+    if (L.k == 5) late_block<5, 6>(a, L, smem, b, last, i);
+    else late_block<3, 6>(a, L, smem, b, last, i);
   }
 }
+
+#ifdef HEP_LATE_TRACE
+extern "C" int hep_dbg_late_trace(unsigned long long* host, int max_words, int enable) {
+  static unsigned long long* buf = nullptr;
+  const size_t cap = (size_t)64 * 16 * LATE_MAX_BLOCKS * 64;      // up to 64 workgroups
+  if (!buf) { if (hipMalloc((void**)&buf, cap * 8) != hipSuccess) return -1; }
+  if (enable) hipMemset(buf, 0, cap * 8);
+  unsigned long long* p = enable ? buf : nullptr;
+  hipMemcpyToSymbol(HIP_SYMBOL(g_late_trace), &p, sizeof p);
+  if (host) { hipDeviceSynchronize(); hipMemcpy(host, buf, (size_t)std::min<size_t>(max_words, cap) * 8, hipMemcpyDeviceToHost); }
+  return (int)cap;
+}
+#endif
 
 // ---- host side ----
 int late_block_supported(int Cin, int Cexp, int N, int k, int stride, int H, int W, int sq) {
   // (KSE = Cin / 32 is a template parameter: 192 input channels - EfficientNet-B0's last stage - is the instantiation that exists)
   return stride == 1 && H == 8 && W == 8 && Cin == 192 && Cexp % LATE_CC == 0 && Cexp <= 2 * LATE_THREADS && (Cexp / 32) % 2 == 0 && N % 8 == 0 && N >= 16 &&
-         (k == 3 || k == 5) && sq >= 1 && sq <= 48 && (N + 15) / 16 <= 21;
+         (k == 3 || k == 5) && sq >= 1 && sq <= 48 && Cexp <= 9 * LATE_CC && (N + 15) / 16 <= 21;
 }
 
 int late_layout(LateArgs* a) {

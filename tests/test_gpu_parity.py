@@ -555,6 +555,54 @@ def test_bf16_plan_variants_are_bit_identical(api, phi, env, monkeypatch):
     s.close()
 
 
+@pytest.mark.parametrize("batch", [16, 3])
+def test_late_block_kernel_alternative_plan(api, batch, monkeypatch):
+    """HEP_LATE=1 (not the default: measured, it ties - DESIGN.md section 2): blocks 12-15 of phi 0 @ 256 as ONE image-resident
+    launch (k_late.hip, one workgroup per image).  The rounding points are those of the launch-by-launch plan, fp32 summation
+    orders differ, so the gate is the teacher-forced one (every block on the device's own input against the bf16-emulating
+    oracle) - and block 12, the first fused block, must sit within a few flipped bf16 roundings of the launch-by-launch plan's."""
+    phi, size, seed = 0, 256, 0
+    sd = api["sd"](phi, seed)
+    x = torch.from_numpy(seeded_input((batch, 3, size, size), seed))
+    s0 = api["Session"](sd, phi, size, batch, "bf16", flags=api["capi"].FLAG_KEEP_INTERMEDIATES)
+    s0.forward(x.cuda())
+    want12 = s0.stage("block12", batch).float().cpu()
+    n0 = len(s0.kernels(batch))
+    s0.close()
+    monkeypatch.setenv("HEP_LATE", "1")
+    s = api["Session"](sd, phi, size, batch, "bf16", flags=api["capi"].FLAG_KEEP_INTERMEDIATES)
+    plan = _plan_syms(s, batch)
+    assert [n for n, y in plan if y == "late_kernel"] == ["b12-b15.blocks"] and len(plan) == n0 - 11, plan
+    s.forward(x.cuda())
+    got12 = s.stage("block12", batch).float().cpu()
+    s.close()
+    d = (got12 - want12).abs()
+    assert d.mean().item() <= 1e-5 * want12.abs().mean().item() and d.max().item() <= 2 ** -6 * want12.abs().max().item(), (d.mean().item(), d.max().item())
+    _teacher_forced_bf16(api, sd, phi, size, batch, x, api["R"].forward(sd, x, phi))
+    # fp32 sessions do not take it
+    sf = api["Session"](sd, phi, size, batch, "fp32")
+    assert not any(y == "late_kernel" for _, y in _plan_syms(sf, batch))
+    sf.close()
+
+
+def test_benchmarked_fp32_plans_are_the_batch_dependent_ones(api):
+    """The fp32 launch plan depends on the batch (rounds of workgroups): the sessions test_fp32_forward_matches_oracle_and_reference_golden
+    runs at phi 0 @ 256 batch 16 and phi 3 @ 512 batch 8 (BASELINE configs 1 and 3) must be the plans bench.py times - multi-pass
+    fronts, two tiles per boundary workgroup, eight-wave split-K project GEMMs and the three-n-tile split-K tile."""
+    s = api["Session"](api["sd"](0, 0), 0, 256, 16, "fp32")
+    plan = dict(_plan_syms(s, 16))
+    s.close()
+    assert plan["b9.front"] == "mbf_kernel<false, 5, 1, 16, false, 1>" and all(plan[f"b{i}.front"].endswith(", 8, false, 1>") for i in (12, 13, 14, 15)), plan
+    assert sum(y.startswith("pw_gemm_kernel<0, ") and y.endswith(", 8>") for y in plan.values()) >= 6, plan          # eight-wave split-K
+    assert plan["b15.project"].startswith("pw_gemm_kernel<0, 2, 3, 2,"), plan                                       # the NT3 split-K tile (batch 16 up)
+    assert sum(y.startswith("xbf_kernel<false") for y in plan.values()) == 2, plan
+    s = api["Session"](api["sd"](3, 0), 3, 512, 8, "fp32")
+    plan3 = dict(_plan_syms(s, 8))
+    s.close()
+    assert sum(y.startswith("mbf_kernel<false") and y.endswith(", 1>") for y in plan3.values()) >= 12, plan3          # multi-pass fronts
+    assert any(y.startswith("xbf_kernel<false") for y in plan3.values()), plan3
+
+
 @pytest.mark.parametrize("size,batch", [(128, 5), (384, 2)])
 def test_other_input_sizes(api, size, batch):
     """Sizes other than the two benchmark ones move every layer onto other kernels (at 128 blocks 1-2 take the small-map
