@@ -180,7 +180,7 @@ def launch_profile(sess, B, ms_step, ms_one_batch, traffic_of=None, layers=True)
     step_bytes = sum(k[1] for k in ks)
     fracs = sorted(k[1] / (t_ * 1e-3) / 1e9 / HBM_PEAK_GBS for k, t_ in zip(ks, per))
     out = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-           "traffic": traffic_of(sym) if traffic_of else None,
+           "traffic": None, "traffic_ratio": None, "traffic_detail": traffic_of(sym) if traffic_of else None,
            "kernel": sym, "launches_per_step": calls, "avg_launch_us": round(t / calls * 1e3, 2),
            "algorithmic_bytes_per_launch": round(nbytes / calls), "share_of_step": round(t / sum(per), 3),
            "measured_with_batches_in_flight": 1,
@@ -192,6 +192,9 @@ def launch_profile(sess, B, ms_step, ms_one_batch, traffic_of=None, layers=True)
            "whole_step_algorithmic_GBps": round(step_bytes / (ms_step * 1e-3) / 1e9, 1),
            "end_to_end_frac": round(step_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
            "end_to_end_frac_one_batch": round(step_bytes / (ms_one_batch * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    if out["traffic_detail"]:      # flat scalars (the driver's record keeps scalars only): HBM bytes per launch from the PMC pass, and over the algorithmic bytes
+        out["traffic"] = out["traffic_detail"]["bytes_per_launch"]
+        out["traffic_ratio"] = round(out["traffic"] / max(1.0, nbytes / calls), 3)
     # context: the next device functions by total time, same definitions
     out["top"] = [{"kernel": k, "launches_per_step": v[3], "avg_launch_us": round(v[0] / v[3] * 1e3, 2), "share_of_step": round(v[0] / sum(per), 3),
                    "achieved": round(v[1] / (v[0] * 1e-3) / 1e9, 1), "frac": round(v[1] / (v[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
@@ -522,10 +525,22 @@ def main():
                 if ok:
                     best = max(ok, key=lambda p: cands[p][0])
                     out["meets_add_bound"] = {"dtype": best, "value": cands[best][0], "unit": "frames/s", "one_batch_in_flight": cands[best][1],
+                                              "timed_steps": {args.precision: args.steps, **({"fp32": out["fp32"]["steps"]} if "fp32" in out else {})},
                                               "add_mm": out["add_vs_ref"][best]["add_mm"], "add_s_mm": out["add_vs_ref"][best]["add_s_mm"], "bound_mm": 0.1,
                                               "what": f"frames/s of the {best} sessions ({D} batches in flight) - the fastest measured precision whose pose stays within 0.1 mm ADD of the reference's"}
                 else:
                     out["meets_add_bound"] = None
+            # the same figures as flat scalars next to the nested blocks (a record that keeps only top-level scalars still carries them)
+            if "fp32" in out:
+                out["fp32_value"] = out["fp32"]["value"]; out["fp32_one_batch"] = out["fp32"]["one_batch_in_flight"]["value"]
+            out["one_batch_value"] = out["one_batch_in_flight"]["value"]
+            if out.get("meets_add_bound"):
+                out["meets_add_bound_value"] = out["meets_add_bound"]["value"]; out["meets_add_bound_dtype"] = out["meets_add_bound"]["dtype"]
+            for p_ in ("bf16", "fp32"):
+                if p_ in out.get("add_vs_ref", {}):
+                    out[f"add_mm_{p_}"] = out["add_vs_ref"][p_]["add_mm"]
+            out["roofline_traffic_ratio"] = out["roofline"]["traffic_ratio"]; out["roofline_traffic_bytes_per_launch"] = out["roofline"]["traffic"]
+            out["roofline_end_to_end_frac"] = out["roofline"]["end_to_end_frac"]; out["roofline_time_weighted_frac"] = out["roofline"]["time_weighted_frac"]
         print(json.dumps(out), flush=True)
     main_loop.close()
     if world > 1:

@@ -413,7 +413,15 @@ int hep_preprocess_i420_device(hep_handle* h, const uint8_t* yuv, int batch, int
       hipFree(s.d_pre[i]); s.d_pre[i] = nullptr; s.pre_bytes[i] = 0;
       HIPRET(hipMalloc((void**)&s.d_pre[i], want[i])); s.pre_bytes[i] = want[i];
     }
+  // (the handle-owned event would become a captured event: a later wait outside the capture may fail - this entry point is
+  //  not for stream capture)
+  {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return fail(HEP_ERR_UNSUPPORTED, "hep_preprocess_i420_device must not be called under stream capture");
+  }
   if (s.pre_pending) HIPRET(hipStreamWaitEvent(st, s.pre_event, 0));
+  // from the first launch on, EVERY return path leaves the event behind the scratch frames' last user
+  struct Guard { Session& s; hipStream_t st; ~Guard() { if (hipEventRecord(s.pre_event, st) == hipSuccess) s.pre_pending = true; } } guard{s, st};
   // Program.cs:161 cvtColor + 383-397 CenterCropAndRescaleMat
   Yv12Args ya; ya.in = yuv; ya.bgr = s.d_pre[0]; ya.B = batch; ya.H = height; ya.W = width; ya.crop = crop;
   ya.ow = (width - crop) / 2; ya.oh = (height - crop) / 2;
@@ -425,11 +433,10 @@ int hep_preprocess_i420_device(hep_handle* h, const uint8_t* yuv, int batch, int
   const float scale = (float)s.size / (float)resized;
   ResizeArgs r2; r2.in = s.d_pre[1]; r2.out = out_hwc; r2.B = batch; r2.H = resized; r2.W = resized; r2.S = s.size; r2.norm = 1;
   r2.nw = s.size; r2.nh = (int)((float)resized * scale);
-  if (r2.nh < 1 || r2.nh > s.size) { hipEventRecord(s.pre_event, st); s.pre_pending = true; return fail(HEP_ERR_UNSUPPORTED, "preprocess: resized frame does not fit the network size"); }
+  if (r2.nh < 1 || r2.nh > s.size) return fail(HEP_ERR_UNSUPPORTED, "preprocess: resized frame does not fit the network size");
   r2.inv_scale_x = (double)resized / r2.nw; r2.inv_scale_y = (double)resized / r2.nh;
   launch_resize_u8(r2, st);
   HIPRET(hipGetLastError());
-  HIPRET(hipEventRecord(s.pre_event, st)); s.pre_pending = true;
   return 0;
 } HEP_CATCH_INT
 

@@ -296,7 +296,9 @@ __global__ __launch_bounds__(CHAIN_THREADS) void chain_kernel(ChainArgs a) {
     for (int pair = wave; pair < mt_n * nt_n; pair += CHAIN_WAVES) {
       const int mt = udiv_rcp(pair, a.nt_rcp), nt = pair - mt * nt_n;      // (host-made reciprocal: a 64-bit division sat here)
       const int m = mt * 16 + r;
-      const T* wrow = (WGLOBAL ? wpw_g : wpw_s) + (int64_t)(nt * 16 + r) * CH + KLANE * g;
+      // (WGLOBAL: at widths that are no multiple of 16 the last n-tile's rows past C would lie behind the node's [C][C + pad] weights
+      //  in the blob - for the last node behind the blob itself; their products are never stored: clamp the row)
+      const T* wrow = (WGLOBAL ? wpw_g : wpw_s) + (int64_t)(WGLOBAL ? min(nt * 16 + r, C - 1) : nt * 16 + r) * CH + KLANE * g;
       const T* arow = atile + (int64_t)m * CH + KLANE * g;
       f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
       if constexpr (WGLOBAL) {

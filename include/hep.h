@@ -209,7 +209,9 @@ int hep_preprocess_u8_device(hep_handle* h, const uint8_t* rgb_hwc, int batch, i
  * the C# Scalars meet a BGR Mat, zero-padded) -> out_hwc float32 [batch, size, size, 3] in B, G, R channel order, the
  * NHWC memory of blobFromImage(swapRB = false)'s NCHW result (hand it to hep_run_device with strides
  * {size*size*3, 1, size*3, 3}).  The app uses crop 256, resized 512.  OpenCV's BT.601 fixed-point conversion and 8-bit
- * INTER_LINEAR are restated from its source: parity unpinned (cv2 is absent from the build image). */
+ * INTER_LINEAR are restated from its source: parity unpinned (cv2 is absent from the build image).
+ * Not for stream capture (the handle orders its scratch frames across streams with an event of its own): HEP_ERR_UNSUPPORTED
+ * when `stream` is capturing. */
 int hep_preprocess_i420_device(hep_handle* h, const uint8_t* yuv, int batch, int height, int width, int crop, int resized,
                                float* out_hwc, void* stream);
 

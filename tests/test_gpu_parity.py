@@ -555,6 +555,51 @@ def test_bf16_plan_variants_are_bit_identical(api, phi, env, monkeypatch):
     s.close()
 
 
+def test_nan_input_reaches_every_fp32_head_as_nan(api):
+    """The fp32 activations use v_rcp_f32 + one Newton step behind a clamp of the denominator (hep_dev.h: rcp_newton): the clamp
+    must let a NaN through (fminf(NaN, c) is c: a NaN logit once came out of the classification sigmoid as ~1e-38 and would
+    have dropped below the score threshold silently).  A poisoned frame is NaN in all five heads, its clean neighbour is untouched."""
+    phi, size = 0, 256
+    sd = api["sd"](phi, 3)
+    x = torch.from_numpy(seeded_input((2, 3, size, size), 5))
+    x[0, :, 100:140, 60:200] = float("nan")
+    for prec in ("fp32", "bf16"):
+        s = api["Session"](sd, phi, size, 2, prec)
+        out = [t.cpu() for t in s.forward(x.cuda())[1:]]
+        ref = [t.cpu() for t in s.forward(x[1:].cuda())[1:]]
+        s.close()
+        for name, t, r in zip(HEADS, out, ref):
+            assert torch.isnan(t[0]).any(), (prec, name, "the poisoned frame came out finite")
+            assert torch.isfinite(t[1]).all() and torch.equal(t[1], r[0]), (prec, name)
+        assert torch.isnan(out[1][0]).float().mean().item() > 0.5, (prec, "classification scores of the poisoned frame")
+
+
+@pytest.mark.parametrize("phi", [1, 2])
+def test_fp32_chains_with_pointwise_weights_from_global_memory(api, phi, monkeypatch):
+    """HEP_CHAIN_STREAM=2 at widths 88 / 112 in fp32 (the planner can pick it at 88): the last n-tile of a node reads weight rows
+    clamped to the node's own [C][C + pad] block (they once ran up to 8 rows past it - past the blob for the last node)."""
+    monkeypatch.setenv("HEP_CHAIN_STREAM", "2")
+    size, batch, seed = 256, 2, 2
+    sd = api["sd"](phi, seed)
+    x = torch.from_numpy(seeded_input((batch, 3, size, size), seed))
+    trace = {}
+    ref = api["R"].forward(sd, x, phi, trace)
+    s = api["Session"](sd, phi, size, batch, "fp32", flags=api["capi"].FLAG_KEEP_INTERMEDIATES)
+    syms = [y for _, y in _plan_syms(s, batch)]
+    out = s.forward(x.cuda())
+    torch.cuda.synchronize()
+    if not any(y == "chain_kernel<false, 2>" for y in syms):
+        s.close()
+        pytest.skip(f"phi {phi}: the planner has no LDS-resident fp32 chain with weights from global memory at this width: {sorted(set(y for y in syms if 'chain' in y or 'sep_kernel<false, 2' in y))}")
+    for name, a, b in zip(HEADS, out[1:], ref[1:]):
+        assert (a.cpu() - b).abs().max().item() <= 1e-3 * max(1.0, b.abs().max().item()), name
+    for k, v in trace.items():
+        if k.startswith("bifpn"):
+            st = s.stage(f"c{k[5:k.index('_')]}.p{k[-1]}_out", batch)
+            assert (st - v.permute(0, 2, 3, 1)).abs().max().item() <= 1e-3 * max(1.0, v.abs().max().item()), k
+    s.close()
+
+
 @pytest.mark.parametrize("batch", [16, 3])
 def test_late_block_kernel_alternative_plan(api, batch, monkeypatch):
     """HEP_LATE=1 (not the default: measured, it ties - DESIGN.md section 2): blocks 12-15 of phi 0 @ 256 as ONE image-resident
@@ -1202,7 +1247,9 @@ def test_rccl_initialises_and_reduces_on_this_box():
         "for q in dist.batch_isend_irecv([dist.P2POp(dist.isend, a, 0), dist.P2POp(dist.irecv, b, 0)]): q.wait()\n"
         "torch.cuda.synchronize(); assert torch.equal(a, b)\n"
         "dist.destroy_process_group(); print('rccl ok')\n")
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29631", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+    import socket
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()      # (a free port: two runs on one host must not collide)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
                HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "rccl ok" in r.stdout and "backend nccl" in r.stdout, (r.stdout[-600:], r.stderr[-1200:])

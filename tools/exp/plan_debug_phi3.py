@@ -1,5 +1,5 @@
 import os, sys
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 os.environ["HEP_PLAN_DEBUG"] = "1"
 import torch
 from hmd_ego_pose_amd.model import Session
