@@ -232,7 +232,7 @@ enum { F_STEM_W, F_STEM_B, F_STEM_OUT, F_PW_A, F_PW_W, F_PW_B, F_PW_RES, F_PW_OU
        F_SEG_SRC, F_SEG_WDW, F_SEG_WPW, F_SEG_BIAS, F_SEG_OUT, F_CH_EXT_SRC, F_CH_EXT_STORE, F_CH_NODE_OUT, F_CH_WBLOB,
        F_SBF_WS, F_SBF_BS, F_SBF_WDW, F_SBF_BDW, F_SBF_STEM, F_SBF_OUT, F_SBF_PART, F_SBF_WR,
        F_XBF_IN, F_XBF_HPART, F_XBF_SEBR, F_XBF_SEWE, F_XBF_SEBE, F_XBF_BLOB, F_XBF_RES, F_XBF_MID, F_XBF_OUT, F_XBF_PART, F_XBF_WR,
-       F_LATE_IN, F_LATE_BLOB, F_LATE_DS, F_LATE_RES, F_LATE_OUT };
+       F_LATE_IN, F_LATE_BLOB, F_LATE_DS, F_LATE_RES, F_LATE_OUT, F_LATE_CNT, F_LATE_HPART };
 
 struct Planner {
   Session* s; const Pack& pk; std::string* err; WBuilder wb; bool ok = true;
@@ -833,11 +833,18 @@ struct Planner {
     }
     const size_t boff = wb.alloc(blob.size());
     memcpy(wb.host.data() + boff, blob.data(), blob.size());
-    const int ds_t = tensor(std::string(nm) + ".dw", 1, 1, 64 * cexp_max);
-    la.dstride = 64 * cexp_max * 2;
+    // workgroups per image (HEP_LATE_G; default 3 where every block's chunk count divides): each runs 1 / G of the chunk loop -
+    // the part that is bound by ONE CU's vector ALU - and they meet once per block (k_late.hip)
+    int G = getenv("HEP_LATE_G") ? atoi(getenv("HEP_LATE_G")) : 3;
+    if (G < 1 || G > 8) G = 1;
+    for (int j = 0; j < n; j++) if (la.blk[j].nchunks % G != 0) G = 1;
+    la.G = G;
+    const int ds_t = tensor(std::string(nm) + ".dw", 1, 1, 64 * cexp_max * (G > 1 ? 2 : 1));
+    la.dstride = 64 * cexp_max * 2 * (G > 1 ? 2 : 1);
+    const int cnt_t = tensor(std::string(nm) + ".cnt", 1, 1, 16, true), hp_t = tensor(std::string(nm) + ".se_part", 1, 1, 2 * 8 * 64, true);
     s->ops[op].late = la;
     wref(op, F_LATE_BLOB, boff);
-    tref(op, F_LATE_IN, x, false); tref(op, F_LATE_DS, ds_t, true);
+    tref(op, F_LATE_IN, x, false); tref(op, F_LATE_DS, ds_t, true); tref(op, F_LATE_CNT, cnt_t, true); tref(op, F_LATE_HPART, hp_t, true);
     for (int j = 0; j < n; j++) {
       tref(op, F_LATE_OUT, outs[j], true, j);
       if (blocks[i0 + j].skip) tref(op, F_LATE_RES, j == 0 ? x : outs[j - 1], false, j);
@@ -1518,6 +1525,8 @@ int build_session(Session* s, const Pack& pack, std::string* err) {
         case F_LATE_IN: o.late.in = ptr; break;
         case F_LATE_BLOB: o.late.blob = (const unsigned char*)ptr; break;
         case F_LATE_DS: o.late.dscratch = ptr; break;
+        case F_LATE_CNT: o.late.counters = (unsigned*)ptr; break;
+        case F_LATE_HPART: o.late.hpart = (float*)ptr; break;
         case F_LATE_RES: o.late.blk[r.seg].res = ptr; break;
         case F_LATE_OUT: o.late.blk[r.seg].out = ptr; break;
       }

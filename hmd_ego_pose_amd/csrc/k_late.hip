@@ -57,6 +57,14 @@ __device__ unsigned long long* g_late_trace = nullptr;
 #endif
 
 __device__ __forceinline__ u32x4 late_ldg(const unsigned char* p) { return *reinterpret_cast<const u32x4*>(p); }
+// Bytes handed from one workgroup of an image's group to the others (depthwise outputs, squeeze-excite partial sums, block outputs
+// read back as residuals): every store write-through (sc0 sc1), every load past the non-coherent caches (sc0 sc1) - the hand-off then
+// needs no release / acquire fence (MI355X_MICROARCH.md, "Valid forms"): the storing waves drain with vmcnt(0), one lane adds to the
+// group's counter, the others poll it.  Raw buffer instructions: the compiler counts them in its own s_waitcnt bookkeeping.
+typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned late_v4;
+typedef __attribute__((__vector_size__(2 * sizeof(unsigned)))) unsigned late_v2;
+#define LATE_COHERENT 17      /* aux bits of the raw buffer builtins on gfx942 / gfx950: sc0 | sc1 */
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t late_rsrc(const void* base) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000); }
 
 // zero the halo positions of both expanded-tile buffers (the interior is rewritten by every chunk, the halo never)
 template <int KS>
@@ -72,12 +80,13 @@ __device__ __forceinline__ void late_zero_halo(unsigned char* smem, const LateAr
 
 // ---- project conv of one block: As[64][Cexp] (LDS, scaled) x Wp -> + bias (+ residual) -> global + next input tile ----
 template <int NTW>
-__device__ __forceinline__ void late_project(const LateArgs& a, const LateBlock& L, unsigned char* smem, int b, bool last_block, int bi) {
+__device__ __forceinline__ void late_project(const LateArgs& a, const LateBlock& L, unsigned char* smem, int b, bool last_block, int bi, int gw) {
   int tid_ = threadIdx.x;
   asm volatile("" : "+v"(tid_));       // (opaque per call: lane-derived addresses are not hoisted to kernel entry and spilled there)
   const int lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6), r = lane & 15, g = lane >> 4;
   const int NG = L.ng, KSP = L.Cexp >> 5, KSH = KSP >> 1, AP = L.Cexp + 8;
   const bool active = wave < 2 * NG;
+  const bool coh = a.G > 1;                                  // the block outputs cross workgroups (written by workgroup 0 of the group, read as residuals by all)
   const int kq = wave >= NG ? 1 : 0, ng = wave - kq * NG;
   const bf16_t* As = reinterpret_cast<const bf16_t*>(smem);
   f32x4 acc[NTW][4];
@@ -96,7 +105,8 @@ __device__ __forceinline__ void late_project(const LateArgs& a, const LateBlock&
         biasv[j] = *reinterpret_cast<const f32x4*>(a.blob + L.off_bp + (size_t)((ng * NTW + j) * 16 + 4 * g) * 4);
 #pragma unroll
         for (int mt = 0; mt < 4; mt++)
-          resv[j][mt] = L.skip ? *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(L.res) + ((size_t)b * 64 + mt * 16 + r) * L.N + n) : (u32x2){0u, 0u};
+          resv[j][mt] = L.skip ? (coh ? __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(late_rsrc(L.res), (int)((((size_t)b * 64 + mt * 16 + r) * L.N + n) * 2), 0, LATE_COHERENT))
+                                     : *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(L.res) + ((size_t)b * 64 + mt * 16 + r) * L.N + n)) : (u32x2){0u, 0u};
       }
     }
   };
@@ -160,7 +170,11 @@ __device__ __forceinline__ void late_project(const LateArgs& a, const LateBlock&
             v[0] += __uint_as_float(rv[0] << 16); v[1] += __uint_as_float(rv[0] & 0xffff0000u);
             v[2] += __uint_as_float(rv[1] << 16); v[3] += __uint_as_float(rv[1] & 0xffff0000u);
           }
-          Vec8<true>::store4(L.out, ((int64_t)b * 64 + m) * L.N + n, v);
+          if (!coh) Vec8<true>::store4(L.out, ((int64_t)b * 64 + m) * L.N + n, v);
+          else if (gw == 0) {
+            u32x2 pk; pk[0] = pack_bf16x2(v[0], v[1]); pk[1] = pack_bf16x2(v[2], v[3]);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(late_v2, pk), late_rsrc(L.out), (int)((((int64_t)b * 64 + m) * L.N + n) * 2), 0, LATE_COHERENT);
+          }
           if (!last_block) Vec8<true>::store4(Xn, (int64_t)m * XPn + n, v);
         }
       }
@@ -171,7 +185,7 @@ __device__ __forceinline__ void late_project(const LateArgs& a, const LateBlock&
 
 // ---- one block ----
 template <int KS, int KSE>
-__device__ __forceinline__ void late_block(const LateArgs& a, const LateBlock& L, unsigned char* smem, int b, bool last_block, int bi) {
+__device__ __forceinline__ void late_block(const LateArgs& a, const LateBlock& L, unsigned char* smem, int b, bool last_block, int bi, int gw) {
   constexpr int PW = KS + 7, PAD = (KS - 1) / 2, KK = KS * KS, KH = (KS + 1) / 2, NXP = KS + 3;
   int tid = threadIdx.x;
   asm volatile("" : "+v"(tid));        // (opaque per block: the compiler hoisted the lane-derived addresses of every instantiation to kernel entry and spilled them)
@@ -179,9 +193,12 @@ __device__ __forceinline__ void late_block(const LateArgs& a, const LateBlock& L
   const bool mm = wave >= LATE_NDW;
   const int ml = tid - LATE_NDW * 64, t = wave - LATE_NDW;      // mm lane index 0..511, n-tile of the chunk
   const int XP = L.Cin + 8, NC = L.nchunks, sqp = L.sqp;
+  const int G = a.G, c_lo = gw * NC / G, c_hi = (gw + 1) * NC / G;      // this workgroup's chunks of the expanded channels
+  const bool coh = G > 1;
   const bf16_t* Xs = reinterpret_cast<const bf16_t*>(smem + a.off_x);
   const unsigned char* blob = a.blob;
-  unsigned char* dimg = reinterpret_cast<unsigned char*>(a.dscratch) + (size_t)b * a.dstride;
+  // (groups: two copies by block parity - a workgroup that is a block ahead writes the copy nobody still reads)
+  unsigned char* dimg = reinterpret_cast<unsigned char*>(a.dscratch) + (size_t)b * a.dstride + (a.G > 1 && (bi & 1) ? (size_t)(a.dstride >> 1) : 0);
   float hacc = 0.f, b1v = 0.f;                                  // mm lanes: reduce-FC partial of hidden unit sj over channel slice spart; its bias
   const int sj = ml >> 3, spart = ml & 7;
   const bool se_lane = mm && sj < sqp;
@@ -203,13 +220,13 @@ __device__ __forceinline__ void late_block(const LateArgs& a, const LateBlock& L
     bdv = late_ldg(blob + L.off_bdw + (size_t)c * LATE_CC * 4 + (size_t)(ml < 32 ? ml : 0) * 16);
   };
   auto park_dw = [&](int c) {
-    unsigned char* wd = smem + a.off_wdw + (c & 1) * a.wdw_stride;
+    unsigned char* wd = smem + a.off_wdw + ((c - c_lo) & 1) * a.wdw_stride;
 #pragma unroll
     for (int i = 0; i < NWV; i++) { const int v = ml + i * LATE_MM_LANES; if (v < KK * 32) *reinterpret_cast<u32x4*>(wd + v * 16) = wdv[i]; }
-    if (ml < 32) *reinterpret_cast<u32x4*>(smem + a.off_bias + (c & 1) * 512 + ml * 16) = bdv;
+    if (ml < 32) *reinterpret_cast<u32x4*>(smem + a.off_bias + ((c - c_lo) & 1) * 512 + ml * 16) = bdv;
   };
   auto expand = [&](int c) {
-    unsigned char* E = smem + a.off_e + (c & 1) * a.e_stride;
+    unsigned char* E = smem + a.off_e + ((c - c_lo) & 1) * a.e_stride;
     f32x4 acc[4] = {bexp, bexp, bexp, bexp};
 #pragma unroll
     for (int ks = 0; ks < KSE; ks++) {
@@ -234,7 +251,7 @@ __device__ __forceinline__ void late_block(const LateArgs& a, const LateBlock& L
     for (int i = 0; i < 4; i++) w1v[i] = *reinterpret_cast<const f32x4*>(p + i * 16);
   };
   auto se_partial = [&](int c) {
-    const f32x4* cs = reinterpret_cast<const f32x4*>(smem + a.off_csum + (c & 1) * 512 + spart * 64);
+    const f32x4* cs = reinterpret_cast<const f32x4*>(smem + a.off_csum + ((c - c_lo) & 1) * 512 + spart * 64);
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; i++) { const f32x4 x = cs[i]; s = fmaf(w1v[i][0], x[0], s); s = fmaf(w1v[i][1], x[1], s); s = fmaf(w1v[i][2], x[2], s); s = fmaf(w1v[i][3], x[3], s); }
@@ -243,9 +260,9 @@ __device__ __forceinline__ void late_block(const LateArgs& a, const LateBlock& L
 
   // ---- dw: depthwise conv of chunk c from E[c & 1] ----
   auto dwconv = [&](int c) {
-    const bf16_t* E = reinterpret_cast<const bf16_t*>(smem + a.off_e + (c & 1) * a.e_stride);
-    const float* wd = reinterpret_cast<const float*>(smem + a.off_wdw + (c & 1) * a.wdw_stride);
-    const float* bd = reinterpret_cast<const float*>(smem + a.off_bias + (c & 1) * 512);
+    const bf16_t* E = reinterpret_cast<const bf16_t*>(smem + a.off_e + ((c - c_lo) & 1) * a.e_stride);
+    const float* wd = reinterpret_cast<const float*>(smem + a.off_wdw + ((c - c_lo) & 1) * a.wdw_stride);
+    const float* bd = reinterpret_cast<const float*>(smem + a.off_bias + ((c - c_lo) & 1) * 512);
     const int yx = lane & 15, cgw = (lane >> 4) & 1, rg = lane >> 5;
     const int cg = wave * 2 + cgw, y = yx >> 1, xh = yx & 1;
     f32x2_t acc[4][4];                                         // [pixel of the strip][channel pair]: every multiply-add is a v_pk_fma_f32
@@ -291,7 +308,7 @@ __device__ __forceinline__ void late_block(const LateArgs& a, const LateBlock& L
         }
       }
     }
-    if (c == 1) LSTAMP(41);
+    if (c == c_lo + 1) LSTAMP(41);
     // the two tap-row halves meet: lanes 0-31 finish pixels 0,1 of the strip, lanes 32-63 pixels 2,3 (first + second)
     float cs8[8];
 #pragma unroll
@@ -308,9 +325,15 @@ __device__ __forceinline__ void late_block(const LateArgs& a, const LateBlock& L
 #pragma unroll
       for (int ch = 0; ch < 8; ch++) cs8[ch] = p ? cs8[ch] + v[ch] : v[ch];
       const int px = y * 8 + xh * 4 + rg * 2 + p;
-      Vec8<true>::store(dimg, ((int64_t)(c * 16 + cg) * 64 + px) * 8, v);
+      if (!coh) Vec8<true>::store(dimg, ((int64_t)(c * 16 + cg) * 64 + px) * 8, v);
+      else {
+        u32x4 pk;
+#pragma unroll
+        for (int q = 0; q < 4; q++) pk[q] = pack_bf16x2(v[2 * q], v[2 * q + 1]);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(late_v4, pk), late_rsrc(dimg), ((c * 16 + cg) * 64 + px) * 16, 0, LATE_COHERENT);
+      }
     }
-    if (c == 1) LSTAMP(42);
+    if (c == c_lo + 1) LSTAMP(42);
     // channel sums over the 32 lanes of this channel group (16 strips x 2 halves): DPP adds inside the 16-lane row (quad, quad pair,
     // half row, row), then the two halves of the wave (fixed order, no LDS round trips: five ds_bpermute per value cost 1 us per chunk)
 #pragma unroll
@@ -324,7 +347,7 @@ __device__ __forceinline__ void late_block(const LateArgs& a, const LateBlock& L
       cs8[ch] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
     }
     if (yx == 0 && rg == 0) {
-      f32x4* d = reinterpret_cast<f32x4*>(smem + a.off_csum + (c & 1) * 512 + cg * 32);
+      f32x4* d = reinterpret_cast<f32x4*>(smem + a.off_csum + ((c - c_lo) & 1) * 512 + cg * 32);
       d[0] = (f32x4){cs8[0], cs8[1], cs8[2], cs8[3]}; d[1] = (f32x4){cs8[4], cs8[5], cs8[6], cs8[7]};
     }
   };
@@ -335,35 +358,35 @@ __device__ __forceinline__ void late_block(const LateArgs& a, const LateBlock& L
     // Every load of an iteration is consumed in the NEXT one (the compiler waits with vmcnt(0) behind the loop edge: a load
     // requested at the top of an iteration and the fragments requested a chunk ago are then waited for together - measured: the
     // expand phase took 4.5 us of a 4.9 us chunk that way and the depthwise waves idled 2 us per chunk at the barrier)
-    load_w(0); load_dw(0);
-    expand(0); park_dw(0);
-    if (NC > 1) { load_w(1); load_dw(1); }
+    load_w(c_lo); load_dw(c_lo);
+    expand(c_lo); park_dw(c_lo);
+    if (c_lo + 1 < c_hi) { load_w(c_lo + 1); load_dw(c_lo + 1); }
     __syncthreads();
     LSTAMP(1);
-    for (int c = 0; c < NC; c++) {
-      if (c == 1) LSTAMP(32);
-      if (c + 1 < NC) expand(c + 1);
-      if (c == 1) LSTAMP(33);
-      if (c >= 1) se_partial(c - 1);                             // (its reduce-FC slice was requested in the previous iteration)
-      if (c == 1) LSTAMP(34);
-      if (c + 1 < NC) park_dw(c + 1);
-      if (c + 2 < NC) { load_w(c + 2); load_dw(c + 2); }
+    for (int c = c_lo; c < c_hi; c++) {
+      if (c == c_lo + 1) LSTAMP(32);
+      if (c + 1 < c_hi) expand(c + 1);
+      if (c == c_lo + 1) LSTAMP(33);
+      if (c > c_lo) se_partial(c - 1);                           // (its reduce-FC slice was requested in the previous iteration)
+      if (c == c_lo + 1) LSTAMP(34);
+      if (c + 1 < c_hi) park_dw(c + 1);
+      if (c + 2 < c_hi) { load_w(c + 2); load_dw(c + 2); }
       load_w1(c);
-      if (c == NC - 1) b1v = *reinterpret_cast<const float*>(blob + L.off_b1 + (size_t)(se_lane ? sj : 0) * 4);
-      if (c == 1) LSTAMP(35);
+      if (c == c_hi - 1) b1v = *reinterpret_cast<const float*>(blob + L.off_b1 + (size_t)(se_lane ? sj : 0) * 4);
+      if (c == c_lo + 1) LSTAMP(35);
       __syncthreads();
-      LSTAMP(8 + c);
+      LSTAMP(8 + c - c_lo);
     }
   } else {
     late_zero_halo<KS>(smem, a);                                // (the depthwise waves: idle until the first chunk is expanded)
     __syncthreads();
     LSTAMP(1);
-    for (int c = 0; c < NC; c++) {
-      if (c == 1) LSTAMP(40);
+    for (int c = c_lo; c < c_hi; c++) {
+      if (c == c_lo + 1) LSTAMP(40);
       dwconv(c);
-      if (c == 1) LSTAMP(43);
+      if (c == c_lo + 1) LSTAMP(43);
       __syncthreads();
-      LSTAMP(8 + c);
+      LSTAMP(8 + c - c_lo);
     }
   }
   LSTAMP(2);
@@ -386,16 +409,43 @@ __device__ __forceinline__ void late_block(const LateArgs& a, const LateBlock& L
   }
   const float b2a = *reinterpret_cast<const float*>(blob + L.off_b2 + (size_t)min(k0, L.Cexp - 1) * 4);
   const float b2b = *reinterpret_cast<const float*>(blob + L.off_b2 + (size_t)min(k1, L.Cexp - 1) * 4);
+  if (!coh) {
 #pragma unroll
-  for (int i = 0; i < NDU; i++) dreg[i] = late_ldg(dimg + (size_t)(tid + LATE_THREADS * min(i, NC - 1)) * 16);
-  if (mm) {
-    se_partial(NC - 1);                                        // (its reduce-FC slice and bias were requested inside the last chunk)
-    float s = hacc;
-    s += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(s), 0xB1, 0xf, 0xf, false));      // the eight channel slices of a hidden unit: lanes 8 j .. 8 j + 7
-    s += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(s), 0x4E, 0xf, 0xf, false));
-    s += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(s), 0x141, 0xf, 0xf, false));
-    if (se_lane && spart == 0) hid_s[sj] = sj < L.sq ? swishf(fmaf(s, L.inv_hw, b1v)) : 0.f;
+    for (int i = 0; i < NDU; i++) dreg[i] = late_ldg(dimg + (size_t)(tid + LATE_THREADS * min(i, NC - 1)) * 16);
   }
+  float hsum = 0.f;
+  if (mm) {
+    se_partial(c_hi - 1);                                      // (its reduce-FC slice and bias were requested inside the last chunk)
+    float sv = hacc;
+    sv += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(sv), 0xB1, 0xf, 0xf, false));    // the eight channel slices of a hidden unit: lanes 8 j .. 8 j + 7
+    sv += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(sv), 0x4E, 0xf, 0xf, false));
+    sv += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(sv), 0x141, 0xf, 0xf, false));
+    hsum = sv;
+  }
+  if (coh) {
+    // ---- the seam of the block: this workgroup's third of the depthwise outputs and of the reduce-FC sums is on its way to memory
+    //      (write-through stores); drain, arrive at the group's counter, wait for the others ----
+    float* hp = a.hpart + ((size_t)(b * 2 + (bi & 1)) * G) * 64;
+    if (se_lane && spart == 0) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(hsum), late_rsrc(hp), (gw * 64 + sj) * 4, 0, LATE_COHERENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      unsigned* cnt = a.counters + (size_t)b * 16;
+      const unsigned target = (unsigned)(bi + 1) * (unsigned)G;
+      __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+    }
+    __syncthreads();
+    LSTAMP(44);
+#pragma unroll
+    for (int i = 0; i < NDU; i++)
+      dreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(late_rsrc(dimg), (tid + LATE_THREADS * min(i, NC - 1)) * 16, 0, LATE_COHERENT));
+    if (se_lane && spart == 0) {
+      hsum = 0.f;
+      for (int q = 0; q < G; q++) hsum += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(late_rsrc(hp), (q * 64 + sj) * 4, 0, LATE_COHERENT));     // (fixed order: every workgroup of the group gets the same bits)
+    }
+  }
+  if (se_lane && spart == 0) hid_s[sj] = sj < L.sq ? swishf(fmaf(hsum, L.inv_hw, b1v)) : 0.f;
   __syncthreads();
   {
     auto row_scale = [&](const u32x4 (&w)[W2V], float be) {
@@ -436,8 +486,8 @@ __device__ __forceinline__ void late_block(const LateArgs& a, const LateBlock& L
   }
   __syncthreads();
   LSTAMP(4);
-  if (L.ntw == 2) late_project<2>(a, L, smem, b, last_block, bi);
-  else late_project<3>(a, L, smem, b, last_block, bi);
+  if (L.ntw == 2) late_project<2>(a, L, smem, b, last_block, bi, gw);
+  else late_project<3>(a, L, smem, b, last_block, bi, gw);
   LSTAMP(5);
 }
 
@@ -448,7 +498,14 @@ __global__ __launch_bounds__(LATE_THREADS) void late_kernel(LateArgs a_by_value)
   (void)a_by_value;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   HEP_POISON(smem, a.lds_bytes);
-  const int b = blockIdx.x;
+  // workgroup -> (image, member of the image's group): the G workgroups of an image get linear ids that are equal mod 8 - the
+  // hardware deals consecutive ids round-robin over the eight XCDs, so a group shares an XCD and its L2 (speed only)
+  int b, gw;
+  {
+    const int L_ = blockIdx.x, G = a.G;
+    if ((a.B & 7) == 0) { const int q = L_ >> 3; gw = q % G; b = (L_ & 7) + 8 * (q / G); }
+    else { b = L_ / G; gw = L_ - b * G; }
+  }
   {   // the first block's input tile: [64][Cin] -> LDS rows of Cin + 8
     const int Cin = a.blk[0].Cin, XP = Cin + 8, vpr = Cin >> 3;
     const unsigned char* src = reinterpret_cast<const unsigned char*>(a.in) + (size_t)b * 64 * Cin * 2;
@@ -462,8 +519,8 @@ __global__ __launch_bounds__(LATE_THREADS) void late_kernel(LateArgs a_by_value)
   for (int i = 0; i < a.nblk; i++) {
     const LateBlock& L = a.blk[i];
     const bool last = i + 1 == a.nblk;
-    if (L.k == 5) late_block<5, 6>(a, L, smem, b, last, i);
-    else late_block<3, 6>(a, L, smem, b, last, i);
+    if (L.k == 5) late_block<5, 6>(a, L, smem, b, last, i, gw);
+    else late_block<3, 6>(a, L, smem, b, last, i, gw);
   }
 }
 
@@ -518,5 +575,7 @@ int late_prepare(void) {
 }
 
 void launch_late(const LateArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(late_kernel, dim3(a.B), dim3(LATE_THREADS), (size_t)a.lds_bytes, s, a);
+  // (groups of G workgroups per image meet once per block at a counter: zeroed in front of every launch - a memset node of the graph)
+  if (a.G > 1) hipMemsetAsync(a.counters, 0, (size_t)a.B * 64, s);
+  hipLaunchKernelGGL(late_kernel, dim3(a.B * a.G), dim3(LATE_THREADS), (size_t)a.lds_bytes, s, a);
 }

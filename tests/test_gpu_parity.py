@@ -600,12 +600,16 @@ def test_fp32_chains_with_pointwise_weights_from_global_memory(api, phi, monkeyp
     s.close()
 
 
-@pytest.mark.parametrize("batch", [16, 3])
-def test_late_block_kernel_alternative_plan(api, batch, monkeypatch):
-    """HEP_LATE=1 (not the default: measured, it ties - DESIGN.md section 2): blocks 12-15 of phi 0 @ 256 as ONE image-resident
-    launch (k_late.hip, one workgroup per image).  The rounding points are those of the launch-by-launch plan, fp32 summation
-    orders differ, so the gate is the teacher-forced one (every block on the device's own input against the bf16-emulating
-    oracle) - and block 12, the first fused block, must sit within a few flipped bf16 roundings of the launch-by-launch plan's."""
+@pytest.mark.parametrize("batch,group", [(16, 3), (16, 1), (3, 3)])
+def test_late_block_kernel_alternative_plan(api, batch, group, monkeypatch):
+    """HEP_LATE=1 (not the default: measured, +1.7 % frames/s with four batches in flight, -4.5 % with one - DESIGN.md section 2):
+    blocks 12-15 of phi 0 @ 256 as ONE image-resident launch (k_late.hip): one workgroup per image (HEP_LATE_G=1), or a group of three
+    that split the expanded channels and meet once per block at a counter in global memory (the default of the alternative; batch 3:
+    the group placement for batches that are no multiple of eight).  The rounding points are those of the launch-by-launch plan,
+    fp32 summation orders differ, so the gate is the teacher-forced one (every block on the device's own input against the
+    bf16-emulating oracle) - and block 12, the first fused block, must sit within a few flipped bf16 roundings of the
+    launch-by-launch plan's.  Two forwards must agree bit for bit (the group's sums meet in a fixed order)."""
+    monkeypatch.setenv("HEP_LATE_G", str(group))
     phi, size, seed = 0, 256, 0
     sd = api["sd"](phi, seed)
     x = torch.from_numpy(seeded_input((batch, 3, size, size), seed))
@@ -618,8 +622,11 @@ def test_late_block_kernel_alternative_plan(api, batch, monkeypatch):
     s = api["Session"](sd, phi, size, batch, "bf16", flags=api["capi"].FLAG_KEEP_INTERMEDIATES)
     plan = _plan_syms(s, batch)
     assert [n for n, y in plan if y == "late_kernel"] == ["b12-b15.blocks"] and len(plan) == n0 - 11, plan
-    s.forward(x.cuda())
+    first = [t.clone() for t in s.forward(x.cuda())[1:]]
     got12 = s.stage("block12", batch).float().cpu()
+    for _ in range(3):
+        again = s.forward(x.cuda())[1:]
+        assert all(torch.equal(a, b) for a, b in zip(first, again)), "two forwards of the grouped launch differ"
     s.close()
     d = (got12 - want12).abs()
     assert d.mean().item() <= 1e-5 * want12.abs().mean().item() and d.max().item() <= 2 ** -6 * want12.abs().max().item(), (d.mean().item(), d.max().item())
