@@ -13,14 +13,18 @@ it runs here:
   ADD / ADD-S                 hep_pose_errors on the GPU (csrc/k_eval.hip; eval/common.py:682-746,
                               calc_min_distances.h:24-35)
   5 cm / 5 degree, t / R diff ``calc_rotation_diff`` etc. below (eval/common.py:750-778,829-833), float64 numpy
+  2D reprojection             ``reprojection_distance`` (eval/common.py:646-679): cv2.projectPoints with zero rotation, translation
+                              and distortion is the pinhole projection u = fx X / Z + cx, v = fy Y / Z + cy (float64)
+  hand joints                 mean end-point error over the 21 joints in mm (eval/common.py:970-982), ground truth from the
+                              dataset's ``hands/<frame>_coords_3d.npy`` (generators/colibri.py:430-436)
   AP                          ``compute_ap`` (eval/common.py:328-354)
 
 ``python -m hmd_ego_pose_amd.evaluate --dataset-path <object folder> --weights ckpt.pth --phi 0`` runs it on a
 supplied dataset; nothing ships with the reference (dataset, checkpoint and mesh are absent), so the numbers of the
 paper cannot be reproduced here - tests drive this module with a synthetic folder.
 
-Not reproduced: the 2D-reprojection metric (cv2.projectPoints) and the hand-vertex error (needs the MANO layer's
-outputs in the dataset's ``hands/`` folder); ``cv2.Rodrigues`` is restated (parity unpinned).
+Not reproduced: the visualisations (draw_samplevis / MANO hand meshes, eval/common.py:449-590); ``cv2.Rodrigues`` and
+``cv2.projectPoints`` are restated (parity unpinned: cv2 is absent from the build image).
 """
 from __future__ import annotations
 
@@ -110,6 +114,17 @@ def calc_rotation_diff(R_gt: np.ndarray, R_pr: np.ndarray) -> float:
     """Angular distance in degrees, eval/common.py:762-778."""
     tr = (np.trace(np.dot(R_pr, R_gt.T)) - 1.0) / 2.0
     return abs(float(np.rad2deg(np.arccos(min(1.0, max(-1.0, tr))))))
+
+
+def reprojection_distance(points: np.ndarray, R_gt: np.ndarray, t_gt: np.ndarray, R_pr: np.ndarray, t_pr: np.ndarray, K: np.ndarray) -> float:
+    """Mean pixel distance between the model points projected with the two poses (check_6d_pose_2d_reprojection,
+    eval/common.py:646-679; correct when <= 5 px).  Pinhole projection, float64."""
+    K = np.asarray(K, dtype=np.float64)
+
+    def project(R, t):
+        p = np.dot(np.asarray(points, np.float64), np.asarray(R, np.float64).T) + np.asarray(t, np.float64).reshape(1, 3)
+        return np.stack([K[0, 0] * p[:, 0] / p[:, 2] + K[0, 2], K[1, 1] * p[:, 1] / p[:, 2] + K[1, 2]], axis=-1)
+    return float(np.linalg.norm(project(R_gt, t_gt) - project(R_pr, t_pr), axis=-1).mean())
 
 
 def pose_errors(points: np.ndarray, rvec_gt: np.ndarray, t_gt: np.ndarray, rvec_pr: np.ndarray, t_pr: np.ndarray,
@@ -205,6 +220,9 @@ class LinemodFolder:
             else:                                     # Linemod's own field: x, y, w, h
                 x, y, w, h = a["obj_bb"]
                 entry["bbox"] = np.array([x, y, x + w, y + h], dtype=np.float32)
+            hands_path = os.path.join(self.object_path, "hands", n[:-len(image_extension)] + "_coords_3d.npy")      # generators/colibri.py:430-436
+            if os.path.exists(hands_path):
+                entry["coords_3d"] = np.load(hands_path).astype(np.float64).reshape(21, 3)
             self.annotations.append(entry)
             self.camera.append(np.array(info[key]["cam_K"], dtype=np.float64).reshape(3, 3))
 
@@ -262,7 +280,8 @@ def evaluate(dataset: LinemodFolder, model, image_size: int, score_threshold: fl
 
     fp, tp, scores = [], [], []
     pairs = []                      # (rvec_gt, t_gt, rvec_pr, t_pr, drill_tip) of every correct 2D detection
-    for i, (boxes, sc, _labels, rots, trans, _hands) in enumerate(all_det):
+    pair_cam, hand_err = [], []     # its camera matrix; mean joint distance in mm where the dataset carries hand joints
+    for i, (boxes, sc, _labels, rots, trans, hands) in enumerate(all_det):
         ann = dataset.annotations[i]
         detected = False
         for d in range(boxes.shape[0]):
@@ -272,6 +291,9 @@ def evaluate(dataset: LinemodFolder, model, image_size: int, score_threshold: fl
                 detected = True
                 fp.append(0); tp.append(1)
                 pairs.append((ann["rotation"], ann["translation"], rots[d].astype(np.float64), trans[d].astype(np.float64), ann["drill_tip"]))
+                pair_cam.append(dataset.camera[i])
+                if "coords_3d" in ann:       # eval/common.py:970-982: mean over the 21 joints of |gt - pred|, metres -> mm
+                    hand_err.append(float(np.linalg.norm(ann["coords_3d"] - hands[d].astype(np.float64).reshape(21, 3), axis=-1).mean() * 1000.0))
             else:
                 fp.append(1); tp.append(0)
     num_ann = float(n)
@@ -287,6 +309,12 @@ def evaluate(dataset: LinemodFolder, model, image_size: int, score_threshold: fl
         r_diff = np.array([calc_rotation_diff(axis_angle_to_matrix(a), axis_angle_to_matrix(b)) for a, b in zip(rg, rp)])
         tip_gt = np.stack([axis_angle_to_matrix(a) @ t[:3] + b for a, b, t in zip(rg, tg, tips)])
         tip_pr = np.stack([axis_angle_to_matrix(a) @ t[:3] + b for a, b, t in zip(rp, tpv, tips)])
+        reproj = np.array([reprojection_distance(dataset.points, axis_angle_to_matrix(a), b, axis_angle_to_matrix(c), d_, K)
+                           for a, b, c, d_, K in zip(rg, tg, rp, tpv, pair_cam)])
+        out["2D_projection"] = float(np.sum(reproj <= 5.0) / num_ann)
+        out["2D_projection_distance_mean"] = float(reproj.mean())
+        if hand_err:
+            out["hand_mean"] = float(np.mean(hand_err)); out["hand_std"] = float(np.std(hand_err))
         out.update({"ADD": float(np.sum(add <= thr) / num_ann), "ADD-S": float(np.sum(add_s <= thr) / num_ann),
                     "5cm_5deg": float(np.sum((t_diff <= 50) & (r_diff <= 5)) / num_ann),
                     "translation_mean": float(t_diff.mean()), "translation_std": float(t_diff.std()),
@@ -295,7 +323,7 @@ def evaluate(dataset: LinemodFolder, model, image_size: int, score_threshold: fl
                     "ADD_distance_mean": float(add.mean()), "ADD_distance_std": float(add.std()),
                     "ADD-S_distance_mean": float(add_s.mean()), "ADD-S_distance_std": float(add_s.std())})
     else:
-        out.update({"ADD": 0.0, "ADD-S": 0.0, "5cm_5deg": 0.0})
+        out.update({"ADD": 0.0, "ADD-S": 0.0, "5cm_5deg": 0.0, "2D_projection": 0.0})
     return out
 
 

@@ -69,7 +69,7 @@ def make_linemod_folder(root, n=5, size=256, seed=0, binary_ply=True):
     from scipy.spatial.transform import Rotation
     rng = np.random.Generator(np.random.PCG64(seed))
     obj = os.path.join(root, "data", "01")
-    for d in ("rgb", "mask"):
+    for d in ("rgb", "mask", "hands"):
         os.makedirs(os.path.join(obj, d), exist_ok=True)
     os.makedirs(os.path.join(root, "models"), exist_ok=True)
     pts = (rng.standard_normal((1500, 3)) * np.array([40.0, 25.0, 60.0])).astype(np.float32)
@@ -96,12 +96,14 @@ def make_linemod_folder(root, n=5, size=256, seed=0, binary_ply=True):
         Image.fromarray(m).save(os.path.join(obj, "mask", f"{i:06d}.png"))
         R = Rotation.from_rotvec(rng.standard_normal(3)).as_matrix()
         t = np.array([rng.normal(0, 40), rng.normal(0, 40), 500 + rng.normal(0, 50)])
+        joints = (rng.standard_normal((21, 3)) * 0.05).astype(np.float64)          # hand joints in metres (generators/colibri.py:430-436)
+        np.save(os.path.join(obj, "hands", f"{i:06d}_coords_3d.npy"), joints)
         gt[i] = [{"cam_R_m2c": [float(v) for v in R.reshape(-1)], "cam_t_m2c": [float(v) for v in t], "obj_bb": [x0, y0, x1 - x0, y1 - y0],
                   "obj_id": 1, "drill_tip_transform": [10.0, -20.0, 30.0, 1.0]}]
         info[i] = {"cam_K": [480.0, 0.0, 128.0, 0.0, 480.0, 128.0, 0.0, 0.0, 1.0], "depth_scale": 1.0}
         if i < n:
             names.append(f"{i:06d}")
-            truth.append(dict(image=img, bbox=np.array([x0, y0, x1, y1], np.float32), R=R, t=t))
+            truth.append(dict(image=img, bbox=np.array([x0, y0, x1, y1], np.float32), R=R, t=t, joints=joints))
     with open(os.path.join(obj, "gt_0.yml"), "w") as f:
         yaml.safe_dump(gt, f)
     with open(os.path.join(obj, "info_0.yml"), "w") as f:

@@ -967,8 +967,9 @@ def test_evaluator_on_a_synthetic_linemod_folder(api, tmp_path):
     res = E.evaluate(ds, model, 256, score_threshold=0.5, max_detections=10, iou_threshold=0.05, batch_size=3, detections_out=dets)
     assert len(dets) == 5 and res["num_annotations"] == 5.0
     # independent recomputation
-    n_ok_add = n_ok_adds = matched = 0
-    for i, (boxes, sc, _l, rots, trans, _h) in enumerate(dets):
+    n_ok_add = n_ok_adds = matched = n_ok_2d = 0
+    hand_mm = []
+    for i, (boxes, sc, _l, rots, trans, hands) in enumerate(dets):
         assert boxes.shape[0] <= 10 and np.all(sc > 0.5) and np.all(np.diff(sc) <= 0)
         ann = ds.annotations[i]
         for d in range(boxes.shape[0]):
@@ -978,9 +979,18 @@ def test_evaluator_on_a_synthetic_linemod_folder(api, tmp_path):
                 ok, _ = D.add_metric(ds.points.astype(np.float64), ds.diameter, Rg, ann["translation"].astype(np.float32).astype(np.float64), Rp, trans[d].astype(np.float64))
                 ok_s, _ = D.add_s_metric(ds.points.astype(np.float64), ds.diameter, Rg, ann["translation"].astype(np.float32).astype(np.float64), Rp, trans[d].astype(np.float64))
                 n_ok_add += ok; n_ok_adds += ok_s
+                # 2D reprojection (eval/common.py:646-679) recomputed point by point, hand joints (eval/common.py:970-982)
+                K = ds.camera[i]
+                px = lambda R_, t_: np.array([[K[0, 0] * q[0] / q[2] + K[0, 2], K[1, 1] * q[1] / q[2] + K[1, 2]] for q in (ds.points.astype(np.float64) @ R_.T + t_)])
+                dist = np.linalg.norm(px(Rg, ann["translation"]) - px(Rp, trans[d].astype(np.float64)), axis=1).mean()
+                n_ok_2d += dist <= 5.0
+                hand_mm.append(np.linalg.norm(ann["coords_3d"] - hands[d].astype(np.float64).reshape(21, 3), axis=1).mean() * 1000.0)
                 break
     assert res["num_matched"] == matched
     assert res["ADD"] == n_ok_add / 5 and res["ADD-S"] == n_ok_adds / 5 and 0.0 <= res["AP"] <= 1.0
+    assert res["2D_projection"] == n_ok_2d / 5
+    if matched:
+        assert abs(res["hand_mean"] - np.mean(hand_mm)) <= 1e-9 * max(1.0, np.mean(hand_mm)) and abs(res["hand_std"] - np.std(hand_mm)) <= 1e-9 * max(1.0, np.std(hand_mm))
 
 
 def test_anchor_targets_match_oracle(api):

@@ -201,6 +201,7 @@ def test_evaluator_host_logic(tmp_path):
         assert np.allclose(E.axis_angle_to_matrix(ds.annotations[i]["rotation"]), t["R"], atol=1e-12)
         assert np.allclose(ds.annotations[i]["translation"], t["t"])
         assert ds.camera_input(i, 1.0).tolist() == [480.0, 480.0, 128.0, 128.0, 1000.0, 1.0]
+        assert np.array_equal(ds.annotations[i]["coords_3d"], t["joints"])          # hands/<frame>_coords_3d.npy (generators/colibri.py:430-436)
     pts2, _ = make_linemod_folder(str(tmp_path / "ds2"), n=1, binary_ply=False)
     assert np.array_equal(E.LinemodFolder(str(tmp_path / "ds2")).points, pts2)
     rng = np.random.Generator(np.random.PCG64(3))
@@ -209,6 +210,12 @@ def test_evaluator_host_logic(tmp_path):
         assert np.allclose(E.axis_angle_to_matrix(rv), R, atol=1e-12) and np.allclose(E.axis_angle_to_matrix(rv), D.rodrigues(rv), atol=1e-15)
         back = E.matrix_to_axis_angle(R)
         assert np.allclose(E.axis_angle_to_matrix(back), R, atol=1e-9), rv
+    # 2D reprojection (eval/common.py:646-679): a pure sideways shift of dx at depth Z moves every projected point by fx * dx / Z pixels
+    P3 = rng.standard_normal((50, 3)) * 10
+    K = np.array([[480.0, 0, 128.0], [0, 470.0, 120.0], [0, 0, 1.0]])
+    assert abs(E.reprojection_distance(P3, np.eye(3), np.array([0, 0, 500.0]), np.eye(3), np.array([0, 0, 500.0]), K)) == 0.0
+    d2 = E.reprojection_distance(np.zeros((3, 3)), np.eye(3), np.array([0, 0, 400.0]), np.eye(3), np.array([2.0, 0, 400.0]), K)
+    assert abs(d2 - 480.0 * 2.0 / 400.0) < 1e-12
     # IoU, +1 convention: identical boxes 1.0; [0,0,9,9] vs [5,5,14,14]: 25 / (100 + 100 - 25)
     ov = E.compute_overlap(np.array([[0, 0, 9, 9], [20, 20, 30, 30]], float), np.array([[0, 0, 9, 9], [5, 5, 14, 14]], float))
     assert ov[0, 0] == 1.0 and abs(ov[0, 1] - 25 / 175) < 1e-15 and ov[1, 0] == 0.0
