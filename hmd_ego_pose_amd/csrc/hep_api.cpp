@@ -50,7 +50,7 @@ Session::~Session() {
   for (hipEvent_t ev : lane_events) hipEventDestroy(ev);
   if (fork_event) hipEventDestroy(fork_event);
   if (pre_event) hipEventDestroy(pre_event);
-  hipFree(d_weights); hipFree(d_arena); hipFree(d_pre[0]); hipFree(d_pre[1]);
+  hipFree(d_sync); hipFree(d_weights); hipFree(d_arena); hipFree(d_pre[0]); hipFree(d_pre[1]);
   for (int i = 0; i < 5; i++) { hipFree(d_out[i]); hipFree(d_feat_nchw[i]); }
   hipFree(d_in); hipFree(d_anchors); hipFree(d_tanchors); hipFree(d_boxes); hipFree(d_trans); hipFree(d_cam);
   hipFree(d_keys); hipFree(d_det);
@@ -828,7 +828,10 @@ int hep_profile_concurrent(hep_handle* h, int batch, int iters, int nstreams, fl
     for (int rep = 0; rep < 2; rep++) {
       auto t0 = std::chrono::steady_clock::now();
       for (int i = 0; i < (rep ? iters : 2); i++)
-        for (auto& x : ss) launch_op(s, s.lane_ops[0][k], s.lane_count(batch, 0), x, s.d_in, st);
+        for (auto& x : ss) {
+          launch_op(s, s.lane_ops[0][k], s.lane_count(batch, 0), x, s.d_in, st);
+          if (s.lane_ops[0][k].kind == OP_LATE && s.lane_ops[0][k].late.G > 1) break;      // (grouped launches of ONE session share its meeting counters: never two at once)
+        }
       for (auto& x : ss) HIPRET(hipStreamSynchronize(x));
       if (rep) per_kernel_ms[k] = (float)(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / (iters * nstreams));
     }

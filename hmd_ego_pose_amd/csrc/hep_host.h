@@ -81,6 +81,7 @@ struct Session {
   uint64_t* d_keys = nullptr; int npow2 = 0;
   float* d_det = nullptr; size_t det_floats = 0;   // staging for host-buffer filter
   float* d_stage[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // host-side inputs of hep_decode / hep_filter (never the forward's outputs)
+  unsigned* d_sync = nullptr;       // meeting counters of grouped launches (k_late.hip): an allocation of its own, zeroed once - never arena memory
   hipStream_t stream = nullptr;     // handle's own stream (host API, capture, profiling)
   std::map<int, std::vector<hipGraphExec_t>> graphs;   // per batch size: one graph per lane
   std::mutex mu;

@@ -176,7 +176,8 @@ struct LateArgs {
   LateBlock blk[LATE_MAX_BLOCKS];
   int nblk, B;
   int G;                        // workgroups per image (1, or a divisor of every block's chunk count): each runs 1 / G of the chunks, one counter meeting per block
-  unsigned* counters;           // [B][16] (one 64-byte line per image), zeroed in front of the launch
+  int cross_xcd;                // HEP_LATE_XCD=1 (tests): a group's workgroups on consecutive ids = different XCDs; default: ids equal mod 8 = one XCD
+  unsigned* counters;           // [B][16] (one 64-byte line per image: a meeting counter per block): zero at session start, kept zero by the kernel
   float* hpart;                 // [B][G][64] squeeze-excite reduce-FC sums of the group's workgroups
   int off_e, e_stride, off_wdw, wdw_stride, off_bias, off_csum, off_x, off_scale, off_hid;   // LDS layout (late_layout): two buffers each of expanded tiles / depthwise weights / biases / channel sums
   int lds_bytes;

@@ -232,7 +232,7 @@ enum { F_STEM_W, F_STEM_B, F_STEM_OUT, F_PW_A, F_PW_W, F_PW_B, F_PW_RES, F_PW_OU
        F_SEG_SRC, F_SEG_WDW, F_SEG_WPW, F_SEG_BIAS, F_SEG_OUT, F_CH_EXT_SRC, F_CH_EXT_STORE, F_CH_NODE_OUT, F_CH_WBLOB,
        F_SBF_WS, F_SBF_BS, F_SBF_WDW, F_SBF_BDW, F_SBF_STEM, F_SBF_OUT, F_SBF_PART, F_SBF_WR,
        F_XBF_IN, F_XBF_HPART, F_XBF_SEBR, F_XBF_SEWE, F_XBF_SEBE, F_XBF_BLOB, F_XBF_RES, F_XBF_MID, F_XBF_OUT, F_XBF_PART, F_XBF_WR,
-       F_LATE_IN, F_LATE_BLOB, F_LATE_DS, F_LATE_RES, F_LATE_OUT, F_LATE_CNT, F_LATE_HPART };
+       F_LATE_IN, F_LATE_BLOB, F_LATE_DS, F_LATE_RES, F_LATE_OUT, F_LATE_HPART };
 
 struct Planner {
   Session* s; const Pack& pk; std::string* err; WBuilder wb; bool ok = true;
@@ -839,12 +839,13 @@ struct Planner {
     if (G < 1 || G > 8) G = 1;
     for (int j = 0; j < n; j++) if (la.blk[j].nchunks % G != 0) G = 1;
     la.G = G;
+    la.cross_xcd = getenv("HEP_LATE_XCD") && atoi(getenv("HEP_LATE_XCD")) != 0;      // 1: a group on consecutive workgroup ids = across XCDs (tests: same bits)
     const int ds_t = tensor(std::string(nm) + ".dw", 1, 1, 64 * cexp_max * (G > 1 ? 2 : 1));
     la.dstride = 64 * cexp_max * 2 * (G > 1 ? 2 : 1);
-    const int cnt_t = tensor(std::string(nm) + ".cnt", 1, 1, 16, true), hp_t = tensor(std::string(nm) + ".se_part", 1, 1, 2 * 8 * 64, true);
+    const int hp_t = tensor(std::string(nm) + ".se_part", 1, 1, 2 * 8 * 64, true);
     s->ops[op].late = la;
     wref(op, F_LATE_BLOB, boff);
-    tref(op, F_LATE_IN, x, false); tref(op, F_LATE_DS, ds_t, true); tref(op, F_LATE_CNT, cnt_t, true); tref(op, F_LATE_HPART, hp_t, true);
+    tref(op, F_LATE_IN, x, false); tref(op, F_LATE_DS, ds_t, true); tref(op, F_LATE_HPART, hp_t, true);
     for (int j = 0; j < n; j++) {
       tref(op, F_LATE_OUT, outs[j], true, j);
       if (blocks[i0 + j].skip) tref(op, F_LATE_RES, j == 0 ? x : outs[j - 1], false, j);
@@ -1441,6 +1442,8 @@ int build_session(Session* s, const Pack& pack, std::string* err) {
     HIPCHK(hipMalloc((void**)&s->d_tanchors, t.size() * 4)); HIPCHK(hipMemcpy(s->d_tanchors, t.data(), t.size() * 4, hipMemcpyHostToDevice));
   }
   HIPCHK(hipEventCreateWithFlags(&s->fork_event, hipEventDisableTiming));
+  HIPCHK(hipMalloc((void**)&s->d_sync, (size_t)s->lanes * s->lane_batch * 64 + 64));
+  HIPCHK(hipMemset(s->d_sync, 0, (size_t)s->lanes * s->lane_batch * 64 + 64));
   // ---- one patched copy of the plan per lane: own arena slice, own slice of the head outputs ----
   s->lane_ops.assign(s->lanes, s->ops);
   for (int lane = 0; lane < s->lanes; lane++) {
@@ -1525,12 +1528,12 @@ int build_session(Session* s, const Pack& pack, std::string* err) {
         case F_LATE_IN: o.late.in = ptr; break;
         case F_LATE_BLOB: o.late.blob = (const unsigned char*)ptr; break;
         case F_LATE_DS: o.late.dscratch = ptr; break;
-        case F_LATE_CNT: o.late.counters = (unsigned*)ptr; break;
         case F_LATE_HPART: o.late.hpart = (float*)ptr; break;
         case F_LATE_RES: o.late.blk[r.seg].res = ptr; break;
         case F_LATE_OUT: o.late.blk[r.seg].out = ptr; break;
       }
     }
+    for (Op& o : ops) if (o.kind == OP_LATE) o.late.counters = s->d_sync + (size_t)lane * s->lane_batch * 16;
     // segment tables to device
     for (Op& o : ops)
       if (o.kind == OP_SEP) {

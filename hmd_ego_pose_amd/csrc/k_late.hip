@@ -87,6 +87,7 @@ __device__ __forceinline__ void late_project(const LateArgs& a, const LateBlock&
   const int NG = L.ng, KSP = L.Cexp >> 5, KSH = KSP >> 1, AP = L.Cexp + 8;
   const bool active = wave < 2 * NG;
   const bool coh = a.G > 1;                                  // the block outputs cross workgroups (written by workgroup 0 of the group, read as residuals by all)
+  const bool timed_out = coh && reinterpret_cast<const int*>(smem + a.off_hid)[63] != 0;      // a meeting of the group timed out (late_block): NaN out
   const int kq = wave >= NG ? 1 : 0, ng = wave - kq * NG;
   const bf16_t* As = reinterpret_cast<const bf16_t*>(smem);
   f32x4 acc[NTW][4];
@@ -105,8 +106,13 @@ __device__ __forceinline__ void late_project(const LateArgs& a, const LateBlock&
         biasv[j] = *reinterpret_cast<const f32x4*>(a.blob + L.off_bp + (size_t)((ng * NTW + j) * 16 + 4 * g) * 4);
 #pragma unroll
         for (int mt = 0; mt < 4; mt++)
-          resv[j][mt] = L.skip ? (coh ? __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(late_rsrc(L.res), (int)((((size_t)b * 64 + mt * 16 + r) * L.N + n) * 2), 0, LATE_COHERENT))
-                                     : *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(L.res) + ((size_t)b * 64 + mt * 16 + r) * L.N + n)) : (u32x2){0u, 0u};
+          if (!L.skip) resv[j][mt] = (u32x2){0u, 0u};
+          else if (!coh) resv[j][mt] = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(L.res) + ((size_t)b * 64 + mt * 16 + r) * L.N + n);
+          else {     // (coherent loads are 16 bytes wide: the aligned pair of this lane's four channels, the lane keeps its half)
+            const int n16 = min((ng * NTW + j) * 16 + 4 * (g & ~1), L.N - 8);
+            const u32x4 rv = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(late_rsrc(L.res), (int)((((size_t)b * 64 + mt * 16 + r) * L.N + n16) * 2), 0, LATE_COHERENT));
+            resv[j][mt] = (g & 1) ? (u32x2){rv[2], rv[3]} : (u32x2){rv[0], rv[1]};
+          }
       }
     }
   };
@@ -164,23 +170,31 @@ __device__ __forceinline__ void late_project(const LateArgs& a, const LateBlock&
           const int m = mt * 16 + r;
           float v[4];
 #pragma unroll
-          for (int q = 0; q < 4; q++) v[q] = s[q] + biasv[j][q];
+          for (int q = 0; q < 4; q++) v[q] = timed_out ? __builtin_nanf("") : s[q] + biasv[j][q];
           if (L.skip) {
             const u32x2 rv = resv[j][mt];
             v[0] += __uint_as_float(rv[0] << 16); v[1] += __uint_as_float(rv[0] & 0xffff0000u);
             v[2] += __uint_as_float(rv[1] << 16); v[3] += __uint_as_float(rv[1] & 0xffff0000u);
           }
           if (!coh) Vec8<true>::store4(L.out, ((int64_t)b * 64 + m) * L.N + n, v);
-          else if (gw == 0) {
-            u32x2 pk; pk[0] = pack_bf16x2(v[0], v[1]); pk[1] = pack_bf16x2(v[2], v[3]);
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(late_v2, pk), late_rsrc(L.out), (int)((((int64_t)b * 64 + m) * L.N + n) * 2), 0, LATE_COHERENT);
-          }
-          if (!last_block) Vec8<true>::store4(Xn, (int64_t)m * XPn + n, v);
+          if (!last_block || coh) Vec8<true>::store4(Xn, (int64_t)m * XPn + n, v);
         }
       }
     }
   }
   __syncthreads();                                           // the next block's input tile is complete, the partial sums are consumed
+  if (coh && gw == 0) {
+    // groups: the block output leaves through the finished LDS tile - consecutive lanes store consecutive 16-byte vectors of the
+    // row-major [64][N] tensor, so every 128-byte line is written whole by one store instruction (the hand-off rule; the other
+    // members read it back as the next block's residual)
+    const bf16_t* Xn = reinterpret_cast<const bf16_t*>(smem + a.off_x);
+    const int XPn = L.N + 8, vpr = L.N >> 3;
+    const float vpr_inv = __builtin_amdgcn_rcpf((float)vpr);
+    for (int u = tid_; u < 64 * vpr; u += LATE_THREADS) {
+      const int m = (int)(((float)u + 0.5f) * vpr_inv), v = u - m * vpr;
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(late_v4, *reinterpret_cast<const u32x4*>(Xn + m * XPn + v * 8)), late_rsrc(L.out), (int)(((size_t)b * 64 * L.N) * 2) + u * 16, 0, LATE_COHERENT);
+    }
+  }
 }
 
 // ---- one block ----
@@ -324,13 +338,14 @@ __device__ __forceinline__ void late_block(const LateArgs& a, const LateBlock& L
       swish_n<true, 8>(v);
 #pragma unroll
       for (int ch = 0; ch < 8; ch++) cs8[ch] = p ? cs8[ch] + v[ch] : v[ch];
-      const int px = y * 8 + xh * 4 + rg * 2 + p;
-      if (!coh) Vec8<true>::store(dimg, ((int64_t)(c * 16 + cg) * 64 + px) * 8, v);
+      const int du = p * 32 + y * 4 + xh * 2 + rg;          // unit of the channel group's 64: [pixel-of-pair p][row y][strip xh][half rg] - for one p the 32
+                                                            // lanes of a channel group write 512 contiguous bytes: whole 128-byte lines per store instruction
+      if (!coh) Vec8<true>::store(dimg, ((int64_t)(c * 16 + cg) * 64 + du) * 8, v);
       else {
         u32x4 pk;
 #pragma unroll
         for (int q = 0; q < 4; q++) pk[q] = pack_bf16x2(v[2 * q], v[2 * q + 1]);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(late_v4, pk), late_rsrc(dimg), ((c * 16 + cg) * 64 + px) * 16, 0, LATE_COHERENT);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(late_v4, pk), late_rsrc(dimg), ((c * 16 + cg) * 64 + du) * 16, 0, LATE_COHERENT);
       }
     }
     if (c == c_lo + 1) LSTAMP(42);
@@ -426,14 +441,34 @@ __device__ __forceinline__ void late_block(const LateArgs& a, const LateBlock& L
     // ---- the seam of the block: this workgroup's third of the depthwise outputs and of the reduce-FC sums is on its way to memory
     //      (write-through stores); drain, arrive at the group's counter, wait for the others ----
     float* hp = a.hpart + ((size_t)(b * 2 + (bi & 1)) * G) * 64;
-    if (se_lane && spart == 0) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(hsum), late_rsrc(hp), (gw * 64 + sj) * 4, 0, LATE_COHERENT);
+    // (hand-off rules of MI355X_MICROARCH.md "Valid forms": every 128-byte line written whole by ONE store instruction of one wave,
+    //  loads of 4 or 16 bytes - the sums go through LDS so that one wave stores the 64 floats)
+    if (se_lane && spart == 0) hid_s[sj] = hsum;
+    __syncthreads();
+    if (wave == 0) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(lane < sqp ? hid_s[lane] : 0.f), late_rsrc(hp), (gw * 64 + lane) * 4, 0, LATE_COHERENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    // (the hand-off does not depend on where the members run: the launch places a group on workgroup ids that are equal mod 8 = one
+    //  XCD and its L2 under round-robin dispatch, for speed; HEP_LATE_XCD=1 places it on consecutive ids = three XCDs and gives the
+    //  same bits - tested)
+    int* timed_out = reinterpret_cast<int*>(smem + a.off_hid) + 63;           // (workgroup-uniform flag, behind the hidden units)
     if (tid == 0) {
-      unsigned* cnt = a.counters + (size_t)b * 16;
-      const unsigned target = (unsigned)(bi + 1) * (unsigned)G;
+      // one counter per block and image (words 0 .. nblk - 1 of the image's 64-byte line), each used once per launch and ZEROED BY
+      // THE KERNEL ITSELF: whoever has passed meeting bi knows that every member has left meeting bi - 1, so member 0 clears that
+      // counter; the last block's counter is cleared at the next launch's first meeting.  The line lives in an allocation of its
+      // own (Session::d_sync, zeroed once), never in the activation arena.
+      // (A hipMemsetAsync in front of the launch did this first: as a memset node of the captured graph it left garbage in the
+      //  upper half of the counter word on every REPLAY - eager launches were fine - every meeting fell through and the groups read
+      //  each other's bytes before they were written: right on the first launch, 10-30 % off on later ones.)
+      unsigned* line = a.counters + (size_t)b * 16;
+      unsigned* cnt = line + bi;
+      if (bi == 0) *timed_out = 0;
       __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+      // (bounded: ~1 s of polling - two launches sharing one session's counters, a misuse, must end in NaN outputs, never in a hung GPU)
+      int spins = 0;
+      while (__hip_atomic_fetch_add(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)G && ++spins < (1 << 20)) __builtin_amdgcn_s_sleep(1);
+      if (spins >= (1 << 20)) *timed_out = 1;
+      if (gw == 0) __hip_atomic_exchange(line + (bi == 0 ? a.nblk - 1 : bi - 1), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     LSTAMP(44);
@@ -469,7 +504,8 @@ __device__ __forceinline__ void late_block(const LateArgs& a, const LateBlock& L
   LSTAMP(3);
   {
     bf16_t* As = reinterpret_cast<bf16_t*>(smem);
-    const int AP = L.Cexp + 8, px = tid & 63;
+    const int AP = L.Cexp + 8, du = tid & 63;
+    const int px = ((du >> 2) & 7) * 8 + ((du >> 1) & 1) * 4 + (du & 1) * 2 + (du >> 5);        // the depthwise waves' unit order (dwconv)
 #pragma unroll
     for (int i = 0; i < NDU; i++) {
       if (i < NC) {
@@ -503,7 +539,7 @@ __global__ __launch_bounds__(LATE_THREADS) void late_kernel(LateArgs a_by_value)
   int b, gw;
   {
     const int L_ = blockIdx.x, G = a.G;
-    if ((a.B & 7) == 0) { const int q = L_ >> 3; gw = q % G; b = (L_ & 7) + 8 * (q / G); }
+    if (G > 1 && !a.cross_xcd) { const int q = L_ >> 3; gw = q % G; b = (L_ & 7) + 8 * (q / G); if (b >= a.B) return; }      // (the grid is padded to whole octets of images)
     else { b = L_ / G; gw = L_ - b * G; }
   }
   {   // the first block's input tile: [64][Cin] -> LDS rows of Cin + 8
@@ -549,7 +585,7 @@ int late_layout(LateArgs* a) {
   for (int i = 0; i < a->nblk; i++) {
     LateBlock& L = a->blk[i];
     kmax = std::max(kmax, L.k); cin_max = std::max(cin_max, L.Cin); cexp_max = std::max(cexp_max, L.Cexp);
-    if (i + 1 < a->nblk) cin_max = std::max(cin_max, L.N);        // the project conv leaves the next input tile where this one was
+    cin_max = std::max(cin_max, L.N);                             // the project conv leaves the next input tile (groups: every block's output tile) where this one was
     const int nt = (L.N + 15) / 16;
     L.ntw = nt <= 16 ? 2 : 3; L.ng = (nt + L.ntw - 1) / L.ntw;
     if (2 * L.ng > LATE_THREADS / 64) return 0;
@@ -575,7 +611,6 @@ int late_prepare(void) {
 }
 
 void launch_late(const LateArgs& a, hipStream_t s) {
-  // (groups of G workgroups per image meet once per block at a counter: zeroed in front of every launch - a memset node of the graph)
-  if (a.G > 1) hipMemsetAsync(a.counters, 0, (size_t)a.B * 64, s);
-  hipLaunchKernelGGL(late_kernel, dim3(a.B * a.G), dim3(LATE_THREADS), (size_t)a.lds_bytes, s, a);
+  const int nwg = a.G > 1 && !a.cross_xcd ? ((a.B + 7) / 8) * 8 * a.G : a.B * a.G;
+  hipLaunchKernelGGL(late_kernel, dim3(nwg), dim3(LATE_THREADS), (size_t)a.lds_bytes, s, a);
 }

@@ -626,7 +626,7 @@ def test_late_block_kernel_alternative_plan(api, batch, group, monkeypatch):
     got12 = s.stage("block12", batch).float().cpu()
     for _ in range(3):
         again = s.forward(x.cuda())[1:]
-        assert all(torch.equal(a, b) for a, b in zip(first, again)), "two forwards of the grouped launch differ"
+        assert all(torch.equal(a, b) for a, b in zip(first, again)), ("two forwards of the grouped launch differ", [(int((a != b).sum()), float((a.float() - b.float()).abs().max()), bool(torch.isfinite(b).all())) for a, b in zip(first, again)])
     s.close()
     d = (got12 - want12).abs()
     assert d.mean().item() <= 1e-5 * want12.abs().mean().item() and d.max().item() <= 2 ** -6 * want12.abs().max().item(), (d.mean().item(), d.max().item())
@@ -635,24 +635,15 @@ def test_late_block_kernel_alternative_plan(api, batch, group, monkeypatch):
     sf = api["Session"](sd, phi, size, batch, "fp32")
     assert not any(y == "late_kernel" for _, y in _plan_syms(sf, batch))
     sf.close()
-
-
-def test_benchmarked_fp32_plans_are_the_batch_dependent_ones(api):
-    """The fp32 launch plan depends on the batch (rounds of workgroups): the sessions test_fp32_forward_matches_oracle_and_reference_golden
-    runs at phi 0 @ 256 batch 16 and phi 3 @ 512 batch 8 (BASELINE configs 1 and 3) must be the plans bench.py times - multi-pass
-    fronts, two tiles per boundary workgroup, eight-wave split-K project GEMMs and the three-n-tile split-K tile."""
-    s = api["Session"](api["sd"](0, 0), 0, 256, 16, "fp32")
-    plan = dict(_plan_syms(s, 16))
-    s.close()
-    assert plan["b9.front"] == "mbf_kernel<false, 5, 1, 16, false, 1>" and all(plan[f"b{i}.front"].endswith(", 8, false, 1>") for i in (12, 13, 14, 15)), plan
-    assert sum(y.startswith("pw_gemm_kernel<0, ") and y.endswith(", 8>") for y in plan.values()) >= 6, plan          # eight-wave split-K
-    assert plan["b15.project"].startswith("pw_gemm_kernel<0, 2, 3, 2,"), plan                                       # the NT3 split-K tile (batch 16 up)
-    assert sum(y.startswith("xbf_kernel<false") for y in plan.values()) == 2, plan
-    s = api["Session"](api["sd"](3, 0), 3, 512, 8, "fp32")
-    plan3 = dict(_plan_syms(s, 8))
-    s.close()
-    assert sum(y.startswith("mbf_kernel<false") and y.endswith(", 1>") for y in plan3.values()) >= 12, plan3          # multi-pass fronts
-    assert any(y.startswith("xbf_kernel<false") for y in plan3.values()), plan3
+    if group > 1 and batch == 3:
+        # the hand-off between a group's members (write-through stores, cache-bypassing loads, a counter) must not depend on where
+        # they run: HEP_LATE_XCD=1 puts them on consecutive workgroup ids = three different XCDs - same bits
+        monkeypatch.setenv("HEP_LATE_XCD", "1")
+        sx = api["Session"](sd, phi, size, batch, "bf16")
+        for _ in range(3):
+            outs = sx.forward(x.cuda())[1:]
+            assert all(torch.equal(a, b) for a, b in zip(first, outs)), "a group spread over XCDs computes other bits"
+        sx.close()
 
 
 @pytest.mark.parametrize("size,batch", [(128, 5), (384, 2)])
