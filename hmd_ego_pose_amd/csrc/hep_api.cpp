@@ -74,6 +74,7 @@ void launch_op(const Session& s, const Op& op, int batch, hipStream_t st, const 
     case OP_SE: { SeFinishArgs a = op.se; a.B = batch; launch_se_finish(a, st); break; }
     case OP_XBF: { XbfArgs a = op.xbf; a.B = batch; launch_xbf(a, st); break; }
     case OP_LATE: { LateArgs a = op.late; a.B = batch; launch_late(a, st); break; }
+    case OP_HEADS: { HeadsArgs a = op.heads; a.B = batch; launch_heads(a, st); break; }
     case OP_SBF: {
       SbfArgs a = op.sbf; a.B = batch; a.in = in;
       a.sn = strides[0]; a.sc = strides[1]; a.sh = strides[2]; a.sw = strides[3];
@@ -740,6 +741,7 @@ int hep_kernel_symbol(const hep_handle* h, int i, const char** symbol) try {
                  break;
     case OP_SBF: snprintf(tmp, sizeof tmp, "sbf_kernel<%s>", t); break;
     case OP_LATE: snprintf(tmp, sizeof tmp, "late_kernel"); break;
+    case OP_HEADS: snprintf(tmp, sizeof tmp, "heads_kernel"); break;
     case OP_XBF: { const int sp = xbf_specialised(o.xbf);
                    snprintf(tmp, sizeof tmp, "xbf_kernel<%s, %d, %d, %d, %d, %d, %d, %d>", t, o.xbf.k, o.xbf.s, o.xbf.toh, o.xbf.tow, o.xbf.NT1, sp ? o.xbf.K1 : 0, sp ? o.xbf.NT2 : 0); break; }
     default: if (o.sep.direct) snprintf(tmp, sizeof tmp, "%s<%s, %d, %s>", o.sep.coop ? "tower_coop_kernel" : "tower_kernel", t, o.sep.C, o.sep.direct == 2 ? "true" : "false");

@@ -45,10 +45,10 @@ struct TensorDesc {
   void* ext_ptr = nullptr;
 };
 
-enum OpKind { OP_STEM, OP_PW, OP_DW, OP_POOL, OP_SEP, OP_MBF, OP_PWG, OP_CHAIN, OP_SE, OP_XBF, OP_SBF, OP_LATE };
+enum OpKind { OP_STEM, OP_PW, OP_DW, OP_POOL, OP_SEP, OP_MBF, OP_PWG, OP_CHAIN, OP_SE, OP_XBF, OP_SBF, OP_LATE, OP_HEADS };
 struct Op {
   OpKind kind; std::string name;
-  StemArgs stem; PwArgs pw; DwArgs dw; PoolArgs pool; SepArgs sep; MbfArgs mbf; PwgArgs pwg; ChainArgs chain; SeFinishArgs se; XbfArgs xbf; SbfArgs sbf; LateArgs late;
+  StemArgs stem; PwArgs pw; DwArgs dw; PoolArgs pool; SepArgs sep; MbfArgs mbf; PwgArgs pwg; ChainArgs chain; SeFinishArgs se; XbfArgs xbf; SbfArgs sbf; LateArgs late; HeadsArgs heads;
   std::vector<SepSeg> segs;         // host copy (device copy uploaded at build)
   std::vector<ChainNode> cnodes;    // host copy of a chain's node table
   std::vector<int> reads, writes;   // tensor ids

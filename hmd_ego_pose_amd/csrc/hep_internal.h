@@ -188,6 +188,27 @@ int late_block_supported(int Cin, int Cexp, int N, int k, int stride, int H, int
 int late_prepare(void);
 void launch_late(const LateArgs&, hipStream_t);
 
+// ---- the five head towers depth-first (k_heads.hip): tower layers + headers of every (net, level) as ONE launch ----
+struct HeadItem {               // one workgroup per image: a 16x16 output tile of one (net, level); a table of these opens the blob
+  int net, level, hw, y0, x0, nhdr;
+  uint32_t off_layers;          // blob offset of the (net, level)'s tower layers: D x { pointwise fragments [n-tile 4][k-step 2][lane 64][8] bf16 (per-level
+                                // BatchNorm folded) | bias [64] f32 | depthwise [9][64] f32, swizzled (0,2,1,3 | 4,6,5,7) per channel octet as k_tower.hip }
+  uint32_t off_hdr[2];          // per header: { depthwise [9][64] f32 swizzled | bias [ntiles * 16] f32 | fragments [ntiles][2][64][8] bf16 }
+  int hdr_ntiles[2], hdr_N[2], hdr_kin[2], hdr_kout[2], hdr_off[2], hdr_act[2], hdr_out[2];
+  int pad_[5];                  // (128 bytes)
+};
+struct HeadsArgs {
+  const void* feat[5];          // the last BiFPN cell's maps [B][hw][hw][64] bf16
+  float* out[5];                // regression, classification, rotation, translation_raw, hand: [B][num_anchors][K]
+  const unsigned char* blob;    // HeadItem table, then the weights
+  int level_off[5];
+  int nitems, B, D, num_anchors, off_wdw, lds_bytes;
+};
+int heads_fused_supported(int C, int depth, int bf16);
+int heads_lds_bytes(int depth, int* off_wdw);
+int heads_prepare(void);
+void launch_heads(const HeadsArgs&, hipStream_t);
+
 // ---- 3x3 s2 max-pool, TF-SAME with ZERO padding (utils_extra.py:72-86) ----
 struct PoolArgs { const void* in; void* out; int B, H, W, C, Ho, Wo, pad_t, pad_l, bf16; };
 

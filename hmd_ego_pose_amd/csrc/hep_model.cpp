@@ -232,7 +232,7 @@ enum { F_STEM_W, F_STEM_B, F_STEM_OUT, F_PW_A, F_PW_W, F_PW_B, F_PW_RES, F_PW_OU
        F_SEG_SRC, F_SEG_WDW, F_SEG_WPW, F_SEG_BIAS, F_SEG_OUT, F_CH_EXT_SRC, F_CH_EXT_STORE, F_CH_NODE_OUT, F_CH_WBLOB,
        F_SBF_WS, F_SBF_BS, F_SBF_WDW, F_SBF_BDW, F_SBF_STEM, F_SBF_OUT, F_SBF_PART, F_SBF_WR,
        F_XBF_IN, F_XBF_HPART, F_XBF_SEBR, F_XBF_SEWE, F_XBF_SEBE, F_XBF_BLOB, F_XBF_RES, F_XBF_MID, F_XBF_OUT, F_XBF_PART, F_XBF_WR,
-       F_LATE_IN, F_LATE_BLOB, F_LATE_DS, F_LATE_RES, F_LATE_OUT, F_LATE_HPART };
+       F_LATE_IN, F_LATE_BLOB, F_LATE_DS, F_LATE_RES, F_LATE_OUT, F_LATE_HPART, F_HEADS_FEAT, F_HEADS_BLOB, F_HEADS_OUT };
 
 struct Planner {
   Session* s; const Pack& pk; std::string* err; WBuilder wb; bool ok = true;
@@ -259,7 +259,7 @@ struct Planner {
   }
   int new_op(OpKind k, const std::string& name) {
     Op o; memset(&o.stem, 0, sizeof o.stem); memset(&o.pw, 0, sizeof o.pw); memset(&o.dw, 0, sizeof o.dw);
-    memset(&o.pool, 0, sizeof o.pool); memset(&o.sep, 0, sizeof o.sep); memset(&o.mbf, 0, sizeof o.mbf); memset(&o.pwg, 0, sizeof o.pwg); memset(&o.chain, 0, sizeof o.chain); memset(&o.se, 0, sizeof o.se); memset(&o.xbf, 0, sizeof o.xbf); memset(&o.sbf, 0, sizeof o.sbf); memset(&o.late, 0, sizeof o.late);
+    memset(&o.pool, 0, sizeof o.pool); memset(&o.sep, 0, sizeof o.sep); memset(&o.mbf, 0, sizeof o.mbf); memset(&o.pwg, 0, sizeof o.pwg); memset(&o.chain, 0, sizeof o.chain); memset(&o.se, 0, sizeof o.se); memset(&o.xbf, 0, sizeof o.xbf); memset(&o.sbf, 0, sizeof o.sbf); memset(&o.late, 0, sizeof o.late); memset(&o.heads, 0, sizeof o.heads);
     o.kind = k; o.name = name;
     s->ops.push_back(o);
     return (int)s->ops.size() - 1;
@@ -982,6 +982,119 @@ struct Planner {
     o.act_bytes_per_image = bytes; o.flops_per_image = flops; o.weight_bytes = wbytes;
   }
 
+  // ---- the five head towers depth-first (k_heads.hip): ONE launch for the tower layers and headers of every net and level ----
+  struct HeaderSpec { int net; std::string key; int kin, kout, off, out, act; };
+  bool add_heads_fused(const std::vector<std::string>& nets, const std::vector<HeaderSpec>& hds, const int feat[5], int depth) {
+    const int C = s->arch.fpn_w;
+    if (!heads_fused_supported(C, depth, s->dtype)) return false;
+    const int op = new_op(OP_HEADS, "heads.fused");
+    HeadsArgs ha; memset(&ha, 0, sizeof ha);
+    ha.D = depth; ha.num_anchors = s->num_anchors;
+    for (int l = 0; l < 5; l++) ha.level_off[l] = s->level_off[l];
+    ha.lds_bytes = heads_lds_bytes(depth, &ha.off_wdw);
+    // items: 16x16 output tiles, sorted by decreasing work - pixels of the tile x (tower layers + the header's n-tiles): the hand net's
+    // tiles of the big levels first (the grid is (images, items): item 0 of every image is dispatched before item 1 of any)
+    std::vector<HeadItem> items;
+    std::vector<double> work;
+    for (int l = 0; l < 5; l++)
+      for (int n = 0; n < (int)nets.size(); n++) {
+        const int hw = s->levels[l];
+        int ncols = 0;
+        for (const HeaderSpec& h : hds) if (h.net == n) ncols += 9 * h.kin;
+        for (int ty = 0; ty < hw; ty += 16) for (int tx = 0; tx < hw; tx += 16) {
+          HeadItem it; memset(&it, 0, sizeof it);
+          it.net = n; it.level = l; it.hw = hw; it.y0 = ty; it.x0 = tx;
+          items.push_back(it);
+          const double px = (double)std::min(16, hw - ty) * std::min(16, hw - tx);
+          work.push_back(px * (depth * 1.6 * 64 + ncols) + 2000);
+        }
+      }
+    {
+      std::vector<int> order(items.size());
+      for (size_t i = 0; i < order.size(); i++) order[i] = (int)i;
+      std::stable_sort(order.begin(), order.end(), [&](int x_, int y_) { return work[x_] > work[y_]; });
+      std::vector<HeadItem> sorted;
+      for (int i : order) sorted.push_back(items[i]);
+      items.swap(sorted);
+    }
+    std::vector<unsigned char> blob(items.size() * sizeof(HeadItem), 0);
+    auto reserve = [&](size_t bytes) { const size_t off = (blob.size() + 15) & ~(size_t)15; blob.resize(off + bytes, 0); return off; };
+    auto put_bf16 = [&](size_t off, size_t idx, float v) { const uint16_t h = f32_to_bf16(v); memcpy(blob.data() + off + idx * 2, &h, 2); };
+    auto put_f32v = [&](size_t off, size_t idx, float v) { memcpy(blob.data() + off + idx * 4, &v, 4); };
+    // depthwise table [9][C] fp32 with k_tower.hip's swizzle: channels (0,2,1,3 | 4,6,5,7) of every octet
+    auto put_dw = [&](size_t off, const PackTensor* wd) {
+      static const int perm[8] = {0, 2, 1, 3, 4, 6, 5, 7};
+      for (int t = 0; t < 9; t++) for (int c = 0; c < C; c++) put_f32v(off, (size_t)t * C + (c & ~7) + (c & 7), wd->data[(size_t)((c & ~7) + perm[c & 7]) * 9 + t]);
+    };
+    // pointwise fragments [n-tile][k-step][lane = (r, g)][8]: W[n = nt*16 + r][k = ks*32 + 8g + e] (rows >= N zero)
+    auto put_frags = [&](size_t off, const PackTensor* wp, int N, int ntiles, const float* scale) {
+      for (int nt = 0; nt < ntiles; nt++) for (int ks = 0; ks < C / 32; ks++) for (int lane = 0; lane < 64; lane++) {
+        const int n = nt * 16 + (lane & 15);
+        if (n >= N) continue;
+        for (int e = 0; e < 8; e++) { const int k = ks * 32 + 8 * (lane >> 4) + e; put_bf16(off, ((size_t)(nt * (C / 32) + ks) * 64 + lane) * 8 + e, wp->data[(size_t)n * C + k] * (scale ? scale[n] : 1.f)); }
+      }
+    };
+    double wbytes = 0, flops = 0, obytes = 0;
+    std::vector<std::vector<size_t>> layer_off(nets.size(), std::vector<size_t>(5, 0));
+    for (size_t n = 0; n < nets.size(); n++)
+      for (int l = 0; l < 5; l++) {
+        const size_t off = reserve((size_t)depth * (8192 + 256 + 2304));
+        layer_off[n][l] = off;
+        for (int i = 0; i < depth; i++) {
+          const std::string key = nets[n] + ".conv_list." + std::to_string(i);
+          const PackTensor* wd = get(key + ".depthwise_conv.conv.weight", {C, 1, 3, 3});
+          const PackTensor* wp = get(key + ".pointwise_conv.conv.weight", {C, C, 1, 1});
+          const PackTensor* bp = get(key + ".pointwise_conv.conv.bias", {C});
+          BnFold bn; if (!fold_bn(pk, nets[n] + ".bn_list." + std::to_string(l) + "." + std::to_string(i), C, &bn, err)) ok = false;
+          if (!ok) return true;
+          const size_t lo = off + (size_t)i * (8192 + 256 + 2304);
+          put_frags(lo, wp, C, 4, bn.scale.data());
+          for (int c = 0; c < C; c++) put_f32v(lo + 8192, c, bp->data[c] * bn.scale[c] + bn.shift[c]);
+          put_dw(lo + 8192 + 256, wd);
+        }
+        wbytes += depth * (8192.0 + 256 + 2304);
+        flops += depth * (2.0 * 9 * s->levels[l] * s->levels[l] * C + 2.0 * s->levels[l] * s->levels[l] * C * C);
+      }
+    std::vector<size_t> hdr_off(hds.size(), 0);
+    for (size_t h = 0; h < hds.size(); h++) {
+      const HeaderSpec& hd = hds[h];
+      const int N = 9 * hd.kin, ntiles = (N + 15) / 16;
+      const PackTensor* wd = get(hd.key + ".depthwise_conv.conv.weight", {C, 1, 3, 3});
+      const PackTensor* wp = get(hd.key + ".pointwise_conv.conv.weight", {N, C, 1, 1});
+      const PackTensor* bp = get(hd.key + ".pointwise_conv.conv.bias", {N});
+      if (!ok) return true;
+      const size_t off = reserve(2304 + (size_t)ntiles * 64 + (size_t)ntiles * 2 * 1024);
+      hdr_off[h] = off;
+      put_dw(off, wd);
+      for (int c = 0; c < N; c++) put_f32v(off + 2304, c, bp->data[c]);
+      put_frags(off + 2304 + (size_t)ntiles * 64, wp, N, ntiles, nullptr);
+      wbytes += 2304.0 + ntiles * (64.0 + 2048);
+      for (int l = 0; l < 5; l++) { flops += 2.0 * 9 * s->levels[l] * s->levels[l] * C + 2.0 * s->levels[l] * s->levels[l] * C * N; obytes += (double)s->levels[l] * s->levels[l] * N * 4; }
+    }
+    for (HeadItem& it : items) {
+      it.off_layers = (uint32_t)layer_off[it.net][it.level];
+      for (size_t h = 0; h < hds.size(); h++)
+        if (hds[h].net == it.net) {
+          const int j = it.nhdr++;
+          if (j >= 2) { *err = "more than two headers on one head net"; ok = false; return true; }
+          it.off_hdr[j] = (uint32_t)hdr_off[h]; it.hdr_N[j] = 9 * hds[h].kin; it.hdr_ntiles[j] = (9 * hds[h].kin + 15) / 16;
+          it.hdr_kin[j] = hds[h].kin; it.hdr_kout[j] = hds[h].kout; it.hdr_off[j] = hds[h].off; it.hdr_act[j] = hds[h].act; it.hdr_out[j] = hds[h].out;
+        }
+    }
+    memcpy(blob.data(), items.data(), items.size() * sizeof(HeadItem));
+    ha.nitems = (int)items.size();
+    const size_t boff = wb.alloc(blob.size());
+    memcpy(wb.host.data() + boff, blob.data(), blob.size());
+    s->ops[op].heads = ha;
+    wref(op, F_HEADS_BLOB, boff);
+    double ibytes = 0;
+    for (int l = 0; l < 5; l++) { tref(op, F_HEADS_FEAT, feat[l], false, l); ibytes += (double)s->levels[l] * s->levels[l] * C * es() * nets.size(); }
+    for (int k = 0; k < 5; k++) refs.push_back({op, F_HEADS_OUT, k, 0, 0, -(k + 2)});   // encoded head output
+    Op& o = s->ops[op];
+    o.act_bytes_per_image = ibytes + obytes; o.weight_bytes = wbytes; o.flops_per_image = flops;
+    return true;
+  }
+
   // ---- LDS-resident chain of small-level BiFPN nodes (k_chain.hip): [optional max-pools of cell 0] + nodes ----
   // pools: {source tensor, output tensor, output level} in order (cell 0: p6_in from p6_pre, p7_in from p6_in).
   // Returns false (nothing added) when the chain does not fit the kernel: the caller then emits the k_sep.hip path.
@@ -1328,8 +1441,17 @@ int build_session(Session* s, const Pack& pack, std::string* err) {
                             {3, "translation_net.initial_translation_xy", 2, 3, 0, 3, ACT_NONE},
                             {3, "translation_net.initial_translation_z", 1, 3, 2, 3, ACT_NONE},
                             {4, "hand_net.initial_hand_coords", 63, 63, 0, 4, ACT_NONE}};
+  // HEP_HEADS_FUSED: 1 = the towers depth-first in ONE launch (k_heads.hip; bf16 at BiFPN width 64), 0 = launch by launch
+  bool heads_done = false;
+  if (getenv("HEP_HEADS_FUSED") ? atoi(getenv("HEP_HEADS_FUSED")) != 0 : false) {
+    std::vector<std::string> nv(nets, nets + 5);
+    std::vector<Planner::HeaderSpec> hv;
+    for (const Hd& h : hds) hv.push_back({h.net, h.key, h.kin, h.kout, h.off, h.out, h.act});
+    heads_done = P.add_heads_fused(nv, hv, feat, A.head_depth);
+    if (!P.ok) return HEP_ERR_PACK;
+  }
   // one launch per tower layer (all five nets x five levels) + one for all headers (k_tower.hip)
-  {
+  if (!heads_done) {
     int cur[5][5];
     for (int n = 0; n < 5; n++) for (int l = 0; l < 5; l++) cur[n][l] = feat[l];
     for (int i = 0; i < A.head_depth; i++) {
@@ -1424,6 +1546,7 @@ int build_session(Session* s, const Pack& pack, std::string* err) {
   if (tower_prepare() != 0) { *err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for tower_kernel"; return HEP_ERR_DEVICE; }
   if (filter_prepare() != 0) { *err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for filter_kernel"; return HEP_ERR_DEVICE; }
   if (sep_prepare() != 0) { *err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"; return HEP_ERR_DEVICE; }
+  if (heads_prepare() != 0) { *err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for heads_kernel"; return HEP_ERR_DEVICE; }
   if (late_prepare() != 0) { *err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for late_kernel"; return HEP_ERR_DEVICE; }
   HIPCHK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
   s->weights_bytes = P.wb.host.size();
@@ -1525,6 +1648,9 @@ int build_session(Session* s, const Pack& pack, std::string* err) {
         case F_XBF_OUT: o.xbf.out = ptr; break;
         case F_XBF_PART: o.xbf.hpart_out = (float*)ptr; break;
         case F_XBF_WR: o.xbf.se_wr = (const float*)ptr; break;
+        case F_HEADS_FEAT: o.heads.feat[r.seg] = ptr; break;
+        case F_HEADS_BLOB: o.heads.blob = (const unsigned char*)ptr; break;
+        case F_HEADS_OUT: o.heads.out[r.seg] = (float*)ptr; break;
         case F_LATE_IN: o.late.in = ptr; break;
         case F_LATE_BLOB: o.late.blob = (const unsigned char*)ptr; break;
         case F_LATE_DS: o.late.dscratch = ptr; break;

@@ -600,6 +600,35 @@ def test_fp32_chains_with_pointwise_weights_from_global_memory(api, phi, monkeyp
     s.close()
 
 
+@pytest.mark.parametrize("size,batch", [(256, 16), (384, 3), (128, 2)])
+def test_depth_first_head_kernel_is_bit_identical(api, size, batch, monkeypatch):
+    """HEP_HEADS_FUSED=1 (not the default: 71 us against 70 us stand-alone, -1.8 % frames/s with four batches in flight - DESIGN.md
+    section 2): the tower layers and headers of all five nets on all five levels as ONE launch (k_heads.hip: a 16x16 output tile per
+    workgroup, the layers in place in LDS, only pixels inside the image computed).  Same arithmetic in the same order as k_tower.hip:
+    the five head outputs must agree bit for bit - on the benchmark shape, on ragged levels (384: 48, 24, 12, 6, 3) and on levels
+    smaller than the tile's halo (128: 16, 8, 4, 2, 1)."""
+    phi, seed = 0, 6
+    sd = api["sd"](phi, seed)
+    x = torch.from_numpy(seeded_input((batch, 3, size, size), seed)).cuda()
+    s0 = api["Session"](sd, phi, size, batch, "bf16")
+    want = [t.clone() for t in s0.forward(x)[1:]]
+    n0 = len(s0.kernels(batch))
+    s0.close()
+    monkeypatch.setenv("HEP_HEADS_FUSED", "1")
+    s = api["Session"](sd, phi, size, batch, "bf16")
+    plan = _plan_syms(s, batch)
+    assert [n for n, y in plan if y == "heads_kernel"] == ["heads.fused"] and len(plan) == n0 - 3 and not any("tower" in y for _, y in plan), plan
+    for _ in range(2):
+        got = s.forward(x)[1:]
+        torch.cuda.synchronize()
+        for name, a, b in zip(HEADS, got, want):
+            assert torch.equal(a, b), f"{name}: {int((a != b).sum())} of {a.numel()} elements differ, max {float((a - b).abs().max()):.3e}"
+    s.close()
+    sf = api["Session"](sd, phi, size, batch, "fp32")      # fp32 sessions keep the launch-by-launch towers
+    assert not any(y == "heads_kernel" for _, y in _plan_syms(sf, batch))
+    sf.close()
+
+
 @pytest.mark.parametrize("batch,group", [(16, 3), (16, 1), (3, 3)])
 def test_late_block_kernel_alternative_plan(api, batch, group, monkeypatch):
     """HEP_LATE=1 (not the default: measured, +1.7 % frames/s with four batches in flight, -4.5 % with one - DESIGN.md section 2):
