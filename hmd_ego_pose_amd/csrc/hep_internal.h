@@ -61,6 +61,7 @@ struct PwArgs {
   int fp8; const float* wscale; float a_scale;   // fp8 operands (k_pw_impl.h): W is e4m3 [tilesN*16][K], per-row scales, per-tensor activation scale
   int mode;            // wave arrangement inside a workgroup: 0 along M, 1 along N, 2 split-K (k_pw.hip)
   int nwv;             // waves per workgroup: 4; 8 for the split-K project convs of fp32 sessions (k_pw_impl.h)
+  int frag;            // A and W are stored in MFMA fragment order ([tile][k-step][lane][8]: k_pw_impl.h FRAG; the front kernel wrote A that way)
   int chunksN; uint32_t chunksN_rcp;   // filled by launch_pw_prec: workgroups along N and rcp_u32() of that
   unsigned long long* trace_buf;   // profiling builds (-DHEP_PW_TRACE): stamps of this launch go here
 };
@@ -106,6 +107,7 @@ struct MbfArgs {
   uint32_t vk_rcp, kpv_rcp;                     // filled by launch_mbf: rcp_u32 of K / 8 and kp / 8
   size_t off_e, off_we, off_w, lds_bytes;
   int fp8; const float* we_scale; float a_scale;   // fp8 sessions: e4m3 expand weights (rows padded to 16 bytes), per-channel / per-tensor scales
+  int out_frag;        // store the output in the project GEMM's fragment order [m-tile = 16 rows of (image, pixel)][k-step][lane][8] (k_pw_impl.h FRAG)
   int trace;           // profiling builds (-DHEP_MBF_TRACE): this launch writes its phase time stamps
   int chunks, tiles_x;                          // filled by launch_mbf: channel chunks per tile, tiles per row
   uint32_t chunks_rcp, tiles_x_rcp, gx_rcp;     // rcp_u32() of chunks, tiles_x, gridDim.x (device: udiv_rcp)

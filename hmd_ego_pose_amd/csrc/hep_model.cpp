@@ -354,7 +354,22 @@ struct Planner {
       std::vector<float> sc;
       wref(op, F_PW_W, wb.put_fp8(wf, tilesN * 16, K, K, &sc)); wref(op, F_PW_WSCALE, wb.put_f32(sc));
       o.pw.fp8 = 1; o.pw.a_scale = 1.f;
-    } else wref(op, F_PW_W, wb.put_typed(wf));
+    } else {
+      // Fragment-ordered operands (k_pw_impl.h FRAG; HEP_PW_FRAG=0 disables): the split-K project convs whose scale comes from
+      // se_finish_kernel and whose activations come from a fused front (k_mbf.hip), K a multiple of the k-step, whole m-tiles per image
+      int producer = -1;
+      for (const Ref& r : refs) if (r.field == F_MBF_OUT && r.tensor == in_t) producer = r.op;
+      const bool frag = s->dtype == 1 && pmode == 2 && pMT == 2 && pNT == 2 && act != ACT_SWISH && se && scale_t >= 0 && K % 32 == 0 && HW % 16 == 0 && producer >= 0 &&
+                        !(getenv("HEP_PW_FRAG") && atoi(getenv("HEP_PW_FRAG")) == 0);
+      if (frag) {
+        std::vector<float> wfr((size_t)tilesN * 16 * K, 0.f);
+        const int kst = K / 32;
+        for (int nt = 0; nt < tilesN; nt++) for (int ks = 0; ks < kst; ks++) for (int lane = 0; lane < 64; lane++) for (int e = 0; e < 8; e++)
+          wfr[(((size_t)nt * kst + ks) * 64 + lane) * 8 + e] = wf[(size_t)(nt * 16 + (lane & 15)) * K + ks * 32 + 8 * (lane >> 4) + e];
+        wref(op, F_PW_W, wb.put_typed(wfr));
+        s->ops[op].pw.frag = 1; s->ops[producer].mbf.out_frag = 1;
+      } else wref(op, F_PW_W, wb.put_typed(wf));
+    }
     wref(op, F_PW_B, wb.put_f32(bf));
     if (res_t >= 0) tref(op, F_PW_RES, res_t, false);
     o.act_bytes_per_image = ((double)HW * K + (double)HW * N * (res_t >= 0 ? 2 : 1)) * es();

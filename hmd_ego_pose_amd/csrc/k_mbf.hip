@@ -584,14 +584,19 @@ __global__ __launch_bounds__(TS == 16 ? 1024 : 512) void mbf_kernel(MbfArgs a) {
       swish_n<BF16, 8>(v);
 #pragma unroll
       for (int c = 0; c < 8; c++) sum[c] += v[c];
-      V::store(a.out, (((int64_t)b * a.Ho + oy) * a.Wo + ox) * a.Cexp + c0 + cg * 8, v);
+      // (out_frag: the project GEMM's fragment order - row m = (image, pixel), 8 channels from k: unit ((m / 16) * (Cexp / 32) + k / 32) * 64 + (k % 32) / 8 * 16 + m % 16)
+      auto oidx = [&](int ox_) -> int64_t {
+        const int m = (b * a.Ho + oy) * a.Wo + ox_, k = c0 + cg * 8;
+        return a.out_frag ? ((int64_t)((m >> 4) * (a.Cexp >> 5) + (k >> 5)) * 64 + ((k & 31) >> 3) * 16 + (m & 15)) * 8 : (int64_t)m * a.Cexp + k;
+      };
+      V::store(a.out, oidx(ox), v);
       if (ox + 1 < a.Wo) {
 #pragma unroll
         for (int c = 0; c < 8; c++) v[c] = acc1[c];
         swish_n<BF16, 8>(v);
 #pragma unroll
         for (int c = 0; c < 8; c++) sum[c] += v[c];
-        V::store(a.out, (((int64_t)b * a.Ho + oy) * a.Wo + ox + 1) * a.Cexp + c0 + cg * 8, v);
+        V::store(a.out, oidx(ox + 1), v);
       }
     }
   }

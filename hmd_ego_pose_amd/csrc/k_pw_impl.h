@@ -71,7 +71,12 @@ extern unsigned long long* g_pw_trace_host;     // device buffer (k_pw.hip); tra
 // their K loop is the exact-fp32 MFMAs (128 MAC per clock and CU: 3.8 us of a wave's 11.8 us at K = 1152) IN SERIES with the
 // fragment loads - one wave per SIMD has nothing to overlap them with.  Eight K slices halve a wave's MFMA chain and put a
 // second wave on every SIMD.  (bf16: measured slower in round 3, 11 us against 9 - its MFMAs are 16 x cheaper.)
-template <int PREC, int MT, int NT, int MODE, int ACT, int SEV, int NWV = 4>
+// FRAG (round 5; bf16 split-K project convs behind a fused front, K a multiple of 32): BOTH operands arrive in MFMA fragment order -
+// the weights host-packed [n-tile][k-step][lane][8], the activations stored that way by the front kernel (k_mbf.hip, MbfArgs::out_frag:
+// [m-tile][k-step][lane][8]) - so every fragment load of a wave is ONE contiguous kilobyte instead of sixteen 64-byte row segments.
+// One CU pulls contiguous fragments at 85-94 GB/s with the loads these kernels keep in flight, row segments at ~41 (tools/wstream,
+// DESIGN.md section 2): the K loop of the late project convs was bound by exactly that.  Same fragments, same order: bit-identical.
+template <int PREC, int MT, int NT, int MODE, int ACT, int SEV, int NWV = 4, bool FRAG = false>
 __global__ __launch_bounds__(NWV * 64) void pw_gemm_kernel(PwArgs a) {
   static_assert(NWV == 4 || (MODE == 2 && (SEV == 0 || SEV == 3)), "eight waves: split-K with the scale copied from se_finish_kernel only");
   constexpr int NTHR = NWV * 64;
@@ -123,7 +128,26 @@ __global__ __launch_bounds__(NWV * 64) void pw_gemm_kernel(PwArgs a) {
     wrow[j] = F8 ? W8 + row : reinterpret_cast<const unsigned char*>(W + row);
   }
   const int klast = max(kend - F::KLANE, 0);
+  // FRAG: fragment (tile, k-step) = 64 lanes x 16 bytes at ((tile * ksteps + k-step) * 64 + lane) * 16
+  const int kst_all = K / F::KSTEP;
+  const raw_t* afr[MT]; const raw_t* wfr[NT];
+  if constexpr (FRAG) {
+    const int mtiles_all = M >> 4;
+#pragma unroll
+    for (int i = 0; i < MT; i++) afr[i] = reinterpret_cast<const raw_t*>(A) + ((size_t)min((m0 >> 4) + i, mtiles_all - 1) * kst_all) * 64 + lane;
+#pragma unroll
+    for (int j = 0; j < NT; j++) wfr[j] = reinterpret_cast<const raw_t*>(W) + ((size_t)min(ntile0 + j, a.tilesN - 1) * kst_all) * 64 + lane;
+  }
   auto load = [&](Step<PREC, MT, NT>& st, int kk) {
+    if constexpr (FRAG) {
+      const bool kok = kk < kend;                                   // (uniform: the slices are whole k-steps)
+      const int ksx = (kok ? kk : max(kend - F::KSTEP, 0)) / F::KSTEP;
+#pragma unroll
+      for (int i = 0; i < MT; i++) { const raw_t v = afr[i][ksx * 64]; st.a[i] = kok ? v : raw_t{}; }
+#pragma unroll
+      for (int j = 0; j < NT; j++) st.w[j] = wfr[j][ksx * 64];
+      return;
+    }
     const int k = kk + F::KLANE * g, kc = min(k, klast);
     const bool kok = k < kend;
 #pragma unroll
@@ -442,6 +466,9 @@ static void launch_nt(const PwArgs& a, dim3 grid, hipStream_t s) {
       else { if (a.NT == 2) hipLaunchKernelGGL((pw_gemm_kernel<PREC, MT, 2, MODE, ACT_NONE, 0, 8>), grid, dim3(512), 0, s, a); else hipLaunchKernelGGL((pw_gemm_kernel<PREC, MT, 1, MODE, ACT_NONE, 0, 8>), grid, dim3(512), 0, s, a); }
       return;
     }
+  }
+  if constexpr (PREC == 1 && MT == 2 && MODE == 2) {
+    if (a.frag && a.NT == 2 && sev == 3 && a.act != ACT_SWISH) { hipLaunchKernelGGL((pw_gemm_kernel<PREC, 2, 2, 2, ACT_NONE, 3, 4, true>), grid, dim3(256), lds, s, a); return; }
   }
   switch (a.NT) {
 #define CASE(n) case n: if (a.act == ACT_SWISH) hipLaunchKernelGGL((pw_gemm_kernel<PREC, MT, n, MODE, ACT_SWISH, 0>), grid, dim3(256), 0, s, a); \

@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""HEP_PW_FRAG=1 (fragment-ordered operands of the late project GEMMs) against HEP_PW_FRAG=0: bit equality of the heads, plan, per-launch times."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np, torch
+from hmd_ego_pose_amd.model import Session
+from hmd_ego_pose_amd.weights import seeded_state_dict
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+sd = seeded_state_dict(0, 0)
+x = torch.from_numpy(np.random.Generator(np.random.PCG64([0, 0x1234])).standard_normal((B, 3, 256, 256)).astype(np.float32)).cuda()
+res = {}
+for fr in ("0", "1"):
+    os.environ["HEP_PW_FRAG"] = fr
+    s = Session(sd, 0, 256, B, "bf16")
+    out = [t.clone() for t in s.forward(x)[1:]]
+    torch.cuda.synchronize()
+    total, per = s.profile(B, 20, per_kernel=True)
+    ks = s.kernels(B)
+    print(f"HEP_PW_FRAG={fr}: one batch {total * 1e3:.1f} us; projects: " + ", ".join(f"{n.split('.')[0]} {t * 1e3:.1f}" for (n, _b, _f, y), t in zip(ks, per) if n.endswith(".project")), " | fronts: " + ", ".join(f"{t * 1e3:.1f}" for (n, _b, _f, y), t in zip(ks, per) if n.endswith(".front")))
+    print("   ", sorted(set(y for n, _b, _f, y in ks if "pw_gemm" in y)))
+    res[fr] = out
+    s.close()
+for n, a, b in zip(("regression", "classification", "rotation", "translation", "hand"), res["0"], res["1"]):
+    print(f"{n}: equal {bool(torch.equal(a, b))} unequal {int((a != b).sum())}")
