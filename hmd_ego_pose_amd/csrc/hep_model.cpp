@@ -277,6 +277,7 @@ struct Planner {
     if (!bnkey.empty() && !fold_bn(pk, bnkey, N, &bn, err)) ok = false;
     if (!ok) return -1;
     const int tilesN = (N + 15) / 16;
+    const bool quant_fp8 = quant && s->dtype == 2;
     std::vector<float> wf((size_t)tilesN * 16 * K, 0.f), bf((size_t)tilesN * 16, 0.f);
     for (int n = 0; n < N; n++) {
       const float sc = bnkey.empty() ? 1.f : bn.scale[n], sh = bnkey.empty() ? 0.f : bn.shift[n];
@@ -359,13 +360,15 @@ struct Planner {
       // se_finish_kernel and whose activations come from a fused front (k_mbf.hip), K a multiple of the k-step, whole m-tiles per image
       int producer = -1;
       for (const Ref& r : refs) if (r.field == F_MBF_OUT && r.tensor == in_t) producer = r.op;
-      const bool frag = s->dtype == 1 && pmode == 2 && pMT == 2 && pNT == 2 && act != ACT_SWISH && se && scale_t >= 0 && K % 32 == 0 && HW % 16 == 0 && producer >= 0 &&
+      const bool frag = s->dtype != 2 && !quant_fp8 && pmode == 2 && pMT == 2 && pNT <= 4 && act != ACT_SWISH && se && HW % 16 == 0 && producer >= 0 &&
                         !(getenv("HEP_PW_FRAG") && atoi(getenv("HEP_PW_FRAG")) == 0);
       if (frag) {
-        std::vector<float> wfr((size_t)tilesN * 16 * K, 0.f);
-        const int kst = K / 32;
-        for (int nt = 0; nt < tilesN; nt++) for (int ks = 0; ks < kst; ks++) for (int lane = 0; lane < 64; lane++) for (int e = 0; e < 8; e++)
-          wfr[(((size_t)nt * kst + ks) * 64 + lane) * 8 + e] = wf[(size_t)(nt * 16 + (lane & 15)) * K + ks * 32 + 8 * (lane >> 4) + e];
+        const int kstep = s->dtype ? 32 : 16, klane = s->dtype ? 8 : 4, kst = (K + kstep - 1) / kstep;
+        std::vector<float> wfr((size_t)tilesN * kst * 64 * klane, 0.f);      // K padded to whole k-steps with zeros
+        for (int nt = 0; nt < tilesN; nt++) for (int ks = 0; ks < kst; ks++) for (int lane = 0; lane < 64; lane++) for (int e = 0; e < klane; e++) {
+          const int k = ks * kstep + klane * (lane >> 4) + e;
+          if (k < K) wfr[(((size_t)nt * kst + ks) * 64 + lane) * klane + e] = wf[(size_t)(nt * 16 + (lane & 15)) * K + k];
+        }
         wref(op, F_PW_W, wb.put_typed(wfr));
         s->ops[op].pw.frag = 1; s->ops[producer].mbf.out_frag = 1;
       } else wref(op, F_PW_W, wb.put_typed(wf));
@@ -537,7 +540,7 @@ struct Planner {
     for (int c = 0; c < b.cexp; c++)
       for (int t = 0; t < b.k * b.k; t++) wdw[(size_t)t * b.cexp + c] = wd->data[(size_t)c * b.k * b.k + t] * bn1.scale[c];
     snprintf(nm, sizeof nm, "b%d.dw", i);
-    const int dw_t = tensor(nm, Ho, Wo, b.cexp);
+    const int dw_t = tensor(nm, Ho, Wo, (b.cexp + 31) & ~31);      // (room for the project GEMM's fragment order: K padded to whole k-steps)
 
     // fused front (expand -> LDS -> depthwise, k_mbf.hip) whenever its LDS tiles fit; the expanded
     // tensor then never reaches HBM.  HEP_NO_MBF=1 forces the two-kernel path (A/B measurements).

@@ -584,19 +584,29 @@ __global__ __launch_bounds__(TS == 16 ? 1024 : 512) void mbf_kernel(MbfArgs a) {
       swish_n<BF16, 8>(v);
 #pragma unroll
       for (int c = 0; c < 8; c++) sum[c] += v[c];
-      // (out_frag: the project GEMM's fragment order - row m = (image, pixel), 8 channels from k: unit ((m / 16) * (Cexp / 32) + k / 32) * 64 + (k % 32) / 8 * 16 + m % 16)
-      auto oidx = [&](int ox_) -> int64_t {
+      // (out_frag: the project GEMM's fragment order - row m = (image, pixel); a 16-byte unit holds KLANE channels from k:
+      //  unit ((m / 16) * ksteps + k / KSTEP) * 64 + (k % KSTEP) / KLANE * 16 + m % 16; fp32: a lane's eight channels are two units)
+      auto ostore = [&](int ox_, const float* vv) {
         const int m = (b * a.Ho + oy) * a.Wo + ox_, k = c0 + cg * 8;
-        return a.out_frag ? ((int64_t)((m >> 4) * (a.Cexp >> 5) + (k >> 5)) * 64 + ((k & 31) >> 3) * 16 + (m & 15)) * 8 : (int64_t)m * a.Cexp + k;
+        if (!a.out_frag) { V::store(a.out, (int64_t)m * a.Cexp + k, vv); return; }
+        constexpr int KST = BF16 ? 32 : 16, KLN = BF16 ? 8 : 4;
+        const int kst = (a.Cexp + KST - 1) / KST;
+#pragma unroll
+        for (int hlf = 0; hlf < 8 / KLN; hlf++) {
+          const int kk = k + hlf * KLN;
+          const int64_t unit = (int64_t)((m >> 4) * kst + kk / KST) * 64 + ((kk % KST) / KLN) * 16 + (m & 15);
+          if constexpr (BF16) V::store(a.out, unit * 8, vv);
+          else V::store4(a.out, unit * 4, vv + hlf * 4);
+        }
       };
-      V::store(a.out, oidx(ox), v);
+      ostore(ox, v);
       if (ox + 1 < a.Wo) {
 #pragma unroll
         for (int c = 0; c < 8; c++) v[c] = acc1[c];
         swish_n<BF16, 8>(v);
 #pragma unroll
         for (int c = 0; c < 8; c++) sum[c] += v[c];
-        V::store(a.out, oidx(ox + 1), v);
+        ostore(ox + 1, v);
       }
     }
   }

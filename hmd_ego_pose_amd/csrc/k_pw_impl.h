@@ -128,8 +128,9 @@ __global__ __launch_bounds__(NWV * 64) void pw_gemm_kernel(PwArgs a) {
     wrow[j] = F8 ? W8 + row : reinterpret_cast<const unsigned char*>(W + row);
   }
   const int klast = max(kend - F::KLANE, 0);
-  // FRAG: fragment (tile, k-step) = 64 lanes x 16 bytes at ((tile * ksteps + k-step) * 64 + lane) * 16
-  const int kst_all = K / F::KSTEP;
+  // FRAG: fragment (tile, k-step) = 64 lanes x 16 bytes at ((tile * ksteps + k-step) * 64 + lane) * 16; K is padded to whole k-steps
+  // (the weights' pad columns are zeros, the activations' are whatever the producer left: zeroed here)
+  const int kst_all = (K + F::KSTEP - 1) / F::KSTEP;
   const raw_t* afr[MT]; const raw_t* wfr[NT];
   if constexpr (FRAG) {
     const int mtiles_all = M >> 4;
@@ -140,8 +141,8 @@ __global__ __launch_bounds__(NWV * 64) void pw_gemm_kernel(PwArgs a) {
   }
   auto load = [&](Step<PREC, MT, NT>& st, int kk) {
     if constexpr (FRAG) {
-      const bool kok = kk < kend;                                   // (uniform: the slices are whole k-steps)
-      const int ksx = (kok ? kk : max(kend - F::KSTEP, 0)) / F::KSTEP;
+      const bool kok = kk < kend && kk + F::KLANE * g < K;          // (kk < kend is uniform: the slices are whole k-steps; the lane test only bites in K's last step)
+      const int ksx = min(kk, max(kend - 1, 0)) / F::KSTEP;
 #pragma unroll
       for (int i = 0; i < MT; i++) { const raw_t v = afr[i][ksx * 64]; st.a[i] = kok ? v : raw_t{}; }
 #pragma unroll
@@ -461,14 +462,27 @@ static void launch_nt(const PwArgs& a, dim3 grid, hipStream_t s) {
   const size_t lds = a.sq > 0 ? ((size_t)a.se_nimg * a.K + a.sqp + 256 + a.sqp) * sizeof(float) : 0;
   const int sev = pw_se_variant(a);
   if constexpr (PREC == 0 && MODE == 2) {
-    if (a.nwv == 8 && a.act != ACT_SWISH && (sev == 0 || sev == 3) && a.NT <= 2) {
+    if (a.nwv == 8 && a.act != ACT_SWISH && (sev == 0 || sev == 3) && a.NT <= 2 && !a.frag) {
       if (sev == 3) { if (a.NT == 2) hipLaunchKernelGGL((pw_gemm_kernel<PREC, MT, 2, MODE, ACT_NONE, 3, 8>), grid, dim3(512), lds, s, a); else hipLaunchKernelGGL((pw_gemm_kernel<PREC, MT, 1, MODE, ACT_NONE, 3, 8>), grid, dim3(512), lds, s, a); }
       else { if (a.NT == 2) hipLaunchKernelGGL((pw_gemm_kernel<PREC, MT, 2, MODE, ACT_NONE, 0, 8>), grid, dim3(512), 0, s, a); else hipLaunchKernelGGL((pw_gemm_kernel<PREC, MT, 1, MODE, ACT_NONE, 0, 8>), grid, dim3(512), 0, s, a); }
       return;
     }
   }
-  if constexpr (PREC == 1 && MT == 2 && MODE == 2) {
-    if (a.frag && a.NT == 2 && sev == 3 && a.act != ACT_SWISH) { hipLaunchKernelGGL((pw_gemm_kernel<PREC, 2, 2, 2, ACT_NONE, 3, 4, true>), grid, dim3(256), lds, s, a); return; }
+  if constexpr (PREC != 2 && MT == 2 && MODE == 2) {
+    if (a.frag && a.act != ACT_SWISH && sev >= 1 && a.NT <= 4) {        // fragment-ordered operands (add_pw decides; hep_kernel_symbol names it)
+      if (PREC == 0 && a.nwv == 8 && sev == 3 && a.NT <= 2) {
+        if (a.NT == 2) hipLaunchKernelGGL((pw_gemm_kernel<PREC, 2, 2, 2, ACT_NONE, 3, 8, true>), grid, dim3(512), lds, s, a);
+        else hipLaunchKernelGGL((pw_gemm_kernel<PREC, 2, 1, 2, ACT_NONE, 3, 8, true>), grid, dim3(512), lds, s, a);
+        return;
+      }
+      switch (a.NT) {
+#define FCASE(n) case n: if (sev == 1) hipLaunchKernelGGL((pw_gemm_kernel<PREC, 2, n, 2, ACT_NONE, 1, 4, true>), grid, dim3(256), lds, s, a); \
+                 else if (sev == 2) hipLaunchKernelGGL((pw_gemm_kernel<PREC, 2, n, 2, ACT_NONE, 2, 4, true>), grid, dim3(256), lds, s, a); \
+                 else hipLaunchKernelGGL((pw_gemm_kernel<PREC, 2, n, 2, ACT_NONE, 3, 4, true>), grid, dim3(256), lds, s, a); return;
+        FCASE(1) FCASE(2) FCASE(3) FCASE(4)
+#undef FCASE
+      }
+    }
   }
   switch (a.NT) {
 #define CASE(n) case n: if (a.act == ACT_SWISH) hipLaunchKernelGGL((pw_gemm_kernel<PREC, MT, n, MODE, ACT_SWISH, 0>), grid, dim3(256), 0, s, a); \

@@ -6,12 +6,15 @@ import numpy as np, torch
 from hmd_ego_pose_amd.model import Session
 from hmd_ego_pose_amd.weights import seeded_state_dict
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
-sd = seeded_state_dict(0, 0)
-x = torch.from_numpy(np.random.Generator(np.random.PCG64([0, 0x1234])).standard_normal((B, 3, 256, 256)).astype(np.float32)).cuda()
+prec = sys.argv[2] if len(sys.argv) > 2 else "bf16"
+phi = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+size = int(sys.argv[4]) if len(sys.argv) > 4 else 256
+sd = seeded_state_dict(phi, 0)
+x = torch.from_numpy(np.random.Generator(np.random.PCG64([0, 0x1234])).standard_normal((B, 3, size, size)).astype(np.float32)).cuda()
 res = {}
 for fr in ("0", "1"):
     os.environ["HEP_PW_FRAG"] = fr
-    s = Session(sd, 0, 256, B, "bf16")
+    s = Session(sd, phi, size, B, prec)
     out = [t.clone() for t in s.forward(x)[1:]]
     torch.cuda.synchronize()
     total, per = s.profile(B, 20, per_kernel=True)
