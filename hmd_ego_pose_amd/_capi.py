@@ -30,6 +30,7 @@ SYMBOLS = {
     "hep_create_from_memory": (c_int, [c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_int, c_uint, POINTER(_P)]),
     "hep_destroy": (None, [_P]),
     "hep_num_anchors": (c_int, [_P]),
+    "hep_num_classes": (c_int, [_P]),
     "hep_output_shape": (c_int, [_P, c_int, c_int, POINTER(c_int64), POINTER(c_int)]),
     "hep_output_device": (c_int, [_P, c_int, POINTER(_FP)]),
     "hep_run": (c_int, [_P, _FP, c_int, POINTER(_FP), _FP, _FP, _FP, _FP, _FP]),

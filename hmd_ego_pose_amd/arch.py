@@ -38,6 +38,7 @@ _FPN_REPEATS = [3, 4, 5, 6, 7, 7, 8, 8, 8]
 _HEAD_DEPTH = [3, 3, 3, 4, 4, 4, 5, 5, 5]
 
 NUM_ANCHORS = 9          # 3 ratios x 3 scales (backbone.py:30-31,45)
+MAX_CLASSES = 63         # the classifier header then is as wide as the hand header (9 * 63 channels): the widest the head kernels are built for
 NUM_LEVELS = 5           # P3..P7 (phi 8 adds P8 and is not supported here)
 HEAD_NAMES = ("regressor", "classifier", "rotation_net", "translation_net", "hand_net")
 OUT_NAMES = ("regression", "classification", "rotation", "translation_raw", "hand")
@@ -179,8 +180,8 @@ BIFPN_FUSION = (("p6_w1", 2), ("p5_w1", 2), ("p4_w1", 2), ("p3_w1", 2),
 def param_spec(phi: int, num_classes: int = 1) -> List[Tuple[str, tuple]]:
     """Ordered (key, shape) list of the reference ``HMDEgoPose(...).state_dict()``
     with ``params['iter'] == 0`` (backbone.py:47-97 registration order)."""
-    if num_classes != 1:
-        raise ValueError("the MI355X path is built for num_classes=1 (the drill), as every reference entry point uses")
+    if not 1 <= int(num_classes) <= MAX_CLASSES:
+        raise ValueError(f"num_classes must be in 1..{MAX_CLASSES}")
     a = get_arch(phi)
     w = a.fpn_w
     out: List[Tuple[str, tuple]] = []
@@ -196,7 +197,7 @@ def param_spec(phi: int, num_classes: int = 1) -> List[Tuple[str, tuple]]:
                          ("p5_to_p6", c5), ("p4_down_channel_2", c4), ("p5_down_channel_2", c5)):
                 out.extend(_lateral(f"{p}.{n}", c, w))
     out.extend(_head("regressor", w, a.head_depth, HEADERS["regressor"]))
-    out.extend(_head("classifier", w, a.head_depth, HEADERS["classifier"]))
+    out.extend(_head("classifier", w, a.head_depth, [("header", NUM_ANCHORS * int(num_classes))]))   # efficientdet/model.py:393
     bb = "backbone_net.model"
     out.append((f"{bb}._conv_stem.conv.weight", (a.stem, 3, 3, 3)))
     out.extend(_bn(f"{bb}._bn0", a.stem))

@@ -22,7 +22,6 @@ static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 #define HIPRET(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(HEP_ERR_DEVICE, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
 
-static const int kOutK[5] = {4, 1, 3, 3, 63};
 
 // Nothing may leave an entry point as a C++ exception (include/hep.h: "never throws"; the C# host P/Invokes these symbols, and
 // ONNXRuntime - the library this one replaces - reports failures through its API, Program.cs:59-61).  Every extern "C" function
@@ -53,7 +52,7 @@ Session::~Session() {
   hipFree(d_sync); hipFree(d_weights); hipFree(d_arena); hipFree(d_pre[0]); hipFree(d_pre[1]);
   for (int i = 0; i < 5; i++) { hipFree(d_out[i]); hipFree(d_feat_nchw[i]); }
   hipFree(d_in); hipFree(d_anchors); hipFree(d_tanchors); hipFree(d_boxes); hipFree(d_trans); hipFree(d_cam);
-  hipFree(d_keys); hipFree(d_det);
+  hipFree(d_keys); hipFree(d_det); hipFree(d_part);
   for (int i = 0; i < 5; i++) hipFree(d_stage[i]);
   if (stream) hipStreamDestroy(stream);
 }
@@ -283,12 +282,13 @@ void hep_destroy(hep_handle* h) try {
 } HEP_CATCH_VOID
 
 int hep_num_anchors(const hep_handle* h) try { return h ? h->s.num_anchors : fail(HEP_ERR_INVALID, "handle is NULL"); } HEP_CATCH_INT
+int hep_num_classes(const hep_handle* h) try { return h ? h->s.num_classes : fail(HEP_ERR_INVALID, "handle is NULL"); } HEP_CATCH_INT
 
 int hep_output_shape(const hep_handle* h, int index, int batch, int64_t dims[4], int* ndim) try {
   if (!h || !dims || index < 0 || index >= HEP_NUM_OUTPUTS) return fail(HEP_ERR_INVALID, "bad argument");
   const Session& s = h->s;
   if (index < 5) { dims[0] = batch; dims[1] = s.arch.fpn_w; dims[2] = s.levels[index]; dims[3] = s.levels[index]; if (ndim) *ndim = 4; }
-  else { dims[0] = batch; dims[1] = s.num_anchors; dims[2] = kOutK[index - 5]; dims[3] = 1; if (ndim) *ndim = 3; }
+  else { dims[0] = batch; dims[1] = s.num_anchors; dims[2] = s.out_k(index - 5); dims[3] = 1; if (ndim) *ndim = 3; }
   return 0;
 } HEP_CATCH_INT
 
@@ -338,7 +338,7 @@ int hep_run_device(hep_handle* h, const float* input, const int64_t in_strides[4
   if (outs)
     for (int i = 0; i < 5; i++)
       if (outs[i] && outs[i] != s.d_out[i])
-        HIPRET(hipMemcpyAsync(outs[i], s.d_out[i], (size_t)batch * s.num_anchors * kOutK[i] * 4, hipMemcpyDeviceToDevice, st));
+        HIPRET(hipMemcpyAsync(outs[i], s.d_out[i], (size_t)batch * s.num_anchors * s.out_k(i) * 4, hipMemcpyDeviceToDevice, st));
   return export_feats(s, batch, feats, true, st);
 } HEP_CATCH_INT
 
@@ -355,7 +355,7 @@ int hep_run(hep_handle* h, const float* input_nchw, int batch, float* const feat
   if (int rc = run_forward(&s, s.d_in, nullptr, batch, s.stream, &err)) return fail(rc, err);
   float* outs[5] = {regression, classification, rotation, translation_raw, hand};
   for (int i = 0; i < 5; i++)
-    if (outs[i]) HIPRET(hipMemcpyAsync(outs[i], s.d_out[i], (size_t)batch * s.num_anchors * kOutK[i] * 4, hipMemcpyDeviceToHost, s.stream));
+    if (outs[i]) HIPRET(hipMemcpyAsync(outs[i], s.d_out[i], (size_t)batch * s.num_anchors * s.out_k(i) * 4, hipMemcpyDeviceToHost, s.stream));
   if (int rc = export_feats(s, batch, feats, false, s.stream)) return rc;
   HIPRET(hipStreamSynchronize(s.stream));
   return 0;
@@ -475,13 +475,14 @@ static int ensure_post(Session& s) {
   if (!s.d_cam) HIPRET(hipMalloc((void**)&s.d_cam, (size_t)s.max_batch * 6 * 4));
   if (!s.d_keys) {
     s.npow2 = 1; while (s.npow2 < s.num_anchors) s.npow2 <<= 1;
-    HIPRET(hipMalloc((void**)&s.d_keys, (size_t)s.max_batch * s.npow2 * 8));
+    HIPRET(hipMalloc((void**)&s.d_keys, (size_t)s.max_batch * s.num_classes * s.npow2 * 8));
   }
+  if (s.num_classes > 1 && !s.d_part) HIPRET(hipMalloc((void**)&s.d_part, (size_t)s.max_batch * s.num_classes * (FILTER_MAX_DET + 1) * 4));
   return 0;
 }
 // staging buffer i (0 regression .. 4 hand, same widths as the outputs) for host-side inputs
 static int ensure_stage(Session& s, int i) {
-  if (!s.d_stage[i]) HIPRET(hipMalloc((void**)&s.d_stage[i], (size_t)s.max_batch * s.num_anchors * kOutK[i] * 4));
+  if (!s.d_stage[i]) HIPRET(hipMalloc((void**)&s.d_stage[i], (size_t)s.max_batch * s.num_anchors * s.out_k(i) * 4));
   return 0;
 }
 
@@ -522,6 +523,7 @@ static int filter_locked(Session& s, const float* boxes, const float* classifica
   a.hand = hand ? hand : s.d_out[4];
   a.B = batch; a.N = s.num_anchors; a.max_det = max_detections; a.score_thr = score_threshold; a.nms_thr = nms_threshold;
   a.keys = s.d_keys; a.npow2 = s.npow2;
+  a.K = s.num_classes; a.part_idx = s.d_part; a.part_cnt = s.d_part ? s.d_part + (size_t)s.max_batch * s.num_classes * FILTER_MAX_DET : nullptr;
   a.det_boxes = det_boxes; a.det_scores = det_scores; a.det_labels = det_labels; a.det_rotation = det_rotation;
   a.det_translation = det_translation; a.det_hand = det_hand; a.det_index = det_index; a.det_count = det_count;
   launch_filter(a, st);

@@ -64,6 +64,8 @@ struct Session {
   std::vector<std::vector<Op>> lane_ops; std::vector<hipStream_t> lane_streams; std::vector<hipEvent_t> lane_events;
   hipEvent_t fork_event = nullptr;
   int levels[5]; int level_off[5]; int num_anchors;
+  int num_classes = 1;              // columns of the classification output: the classifier header holds 9 * num_classes channels (efficientdet/model.py:393)
+  int out_k(int i) const { static const int k[5] = {4, 1, 3, 3, 63}; return i == 1 ? num_classes : k[i]; }   // values per anchor of head output i
   std::vector<TensorDesc> tensors;
   std::vector<Op> ops;
   std::unordered_map<std::string, int> tensor_by_name;
@@ -79,6 +81,7 @@ struct Session {
   float* d_anchors = nullptr; float* d_tanchors = nullptr;
   float* d_boxes = nullptr; float* d_trans = nullptr; float* d_cam = nullptr;
   uint64_t* d_keys = nullptr; int npow2 = 0;
+  int32_t* d_part = nullptr;        // per-class survivors of the detection filter (num_classes > 1)
   float* d_det = nullptr; size_t det_floats = 0;   // staging for host-buffer filter
   float* d_stage[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // host-side inputs of hep_decode / hep_filter (never the forward's outputs)
   unsigned* d_sync = nullptr;       // meeting counters of grouped launches (k_late.hip): an allocation of its own, zeroed once - never arena memory

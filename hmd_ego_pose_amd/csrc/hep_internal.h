@@ -288,10 +288,14 @@ void launch_resize_u8(const ResizeArgs&, hipStream_t);
 struct ExportArgs { const void* in; float* out; int B, H, W, C, bf16; };
 
 // ---- detection filter (layers.py:264-400) ----
+#define FILTER_MAX_DET 256        // max_detections cap (63 classes x 256 survivors still sort in LDS)
 struct FilterArgs {
   const float* boxes; const float* scores; const float* rotation; const float* translation; const float* hand;
   int B, N, max_det; float score_thr, nms_thr;
-  uint64_t* keys;      // workspace [B][Npow2] sort keys
+  int K;               // classes: scores are [B][N][K]; one workgroup per (image, class)
+  int32_t* part_idx;   // K > 1: [B][K][max_det] anchors kept per class, in NMS order; part_cnt [B][K] (filter_merge_kernel reads them)
+  int32_t* part_cnt;
+  uint64_t* keys;      // workspace [B * K][Npow2] sort keys
   int npow2;
   float* det_boxes; float* det_scores; int32_t* det_labels; float* det_rotation; float* det_translation;
   float* det_hand; int32_t* det_index; int32_t* det_count;

@@ -1293,6 +1293,13 @@ int build_session(Session* s, const Pack& pack, std::string* err) {
   int off = 0;
   for (int l = 0; l < 5; l++) { s->levels[l] = (S + (1 << (l + 3)) - 1) >> (l + 3); s->level_off[l] = off; off += s->levels[l] * s->levels[l] * 9; }
   s->num_anchors = off;
+  {   // classes: whatever the classifier's header was trained with (num_anchors * num_classes channels, efficientdet/model.py:393)
+    auto it = pack.tensors.find("classifier.header.pointwise_conv.conv.weight");
+    if (it == pack.tensors.end() || it->second.dims.size() != 4) { *err = "weight pack: missing tensor 'classifier.header.pointwise_conv.conv.weight'"; return HEP_ERR_PACK; }
+    const int64_t n = it->second.dims[0];
+    if (n < 9 || n % 9 || n / 9 > 63) { *err = "weight pack: the classifier header must hold 9 * num_classes channels, num_classes in 1..63"; return HEP_ERR_PACK; }
+    s->num_classes = (int)(n / 9);
+  }
 
   // ---- stem ----
   int H = (S + 1) / 2, W = (S + 1) / 2;
@@ -1454,7 +1461,8 @@ int build_session(Session* s, const Pack& pack, std::string* err) {
   // ---- heads ----
   static const char* nets[5] = {"regressor", "classifier", "rotation_net", "translation_net", "hand_net"};
   struct Hd { int net; const char* key; int kin, kout, off, out, act; };
-  static const Hd hds[6] = {{0, "regressor.header", 4, 4, 0, 0, ACT_NONE}, {1, "classifier.header", 1, 1, 0, 1, ACT_SIGMOID},
+  const int NC = s->num_classes;     // per anchor the classifier emits one column per class (efficientdet/model.py:406-408)
+  const Hd hds[6] = {{0, "regressor.header", 4, 4, 0, 0, ACT_NONE}, {1, "classifier.header", NC, NC, 0, 1, ACT_SIGMOID},
                             {2, "rotation_net.initial_rotation", 3, 3, 0, 2, ACT_NONE},
                             {3, "translation_net.initial_translation_xy", 2, 3, 0, 3, ACT_NONE},
                             {3, "translation_net.initial_translation_z", 1, 3, 2, 3, ACT_NONE},
@@ -1575,8 +1583,7 @@ int build_session(Session* s, const Pack& pack, std::string* err) {
 #ifdef HEP_POISON_LDS     // sanitizer build: activation cells nobody has written yet read as NaN (0xFFFF / 0xFFFFFFFF)
   HIPCHK(hipMemset(s->d_arena, 0xFF, std::max<size_t>(s->arena_bytes * s->lanes, 256)));
 #endif
-  static const int outk[5] = {4, 1, 3, 3, 63};
-  for (int i = 0; i < 5; i++) HIPCHK(hipMalloc((void**)&s->d_out[i], (size_t)s->max_batch * s->num_anchors * outk[i] * 4));
+  for (int i = 0; i < 5; i++) HIPCHK(hipMalloc((void**)&s->d_out[i], (size_t)s->max_batch * s->num_anchors * s->out_k(i) * 4));
   {
     std::vector<float> a, t; host_anchors(S, &a, &t);
     HIPCHK(hipMalloc((void**)&s->d_anchors, a.size() * 4)); HIPCHK(hipMemcpy(s->d_anchors, a.data(), a.size() * 4, hipMemcpyHostToDevice));
@@ -1595,7 +1602,7 @@ int build_session(Session* s, const Pack& pack, std::string* err) {
       Op& o = ops[r.op];
       void* ptr;
       if (r.tensor >= 0) ptr = s->tptr(r.tensor, lane);
-      else if (r.tensor <= -2) { const int k = -(r.tensor + 2); ptr = s->d_out[k] + (size_t)lane * s->lane_batch * s->num_anchors * outk[k]; }
+      else if (r.tensor <= -2) { const int k = -(r.tensor + 2); ptr = s->d_out[k] + (size_t)lane * s->lane_batch * s->num_anchors * s->out_k(k); }
       else ptr = s->d_weights + r.woff;
       switch (r.field) {
         case F_STEM_W: o.stem.w = (const float*)ptr; break;

@@ -49,8 +49,9 @@ void launch_decode(const DecodeArgs& a, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// filter_detections (reference hmdegopose/layers.py:264-400) for num_classes == 1, one workgroup
-// (1024 lanes) per image:
+// filter_detections (reference hmdegopose/layers.py:264-400), class_specific_filter=True (the only mode the reference
+// constructs, train.py:78-81): one workgroup (1024 lanes) per (image, class); with more than one class
+// filter_merge_kernel then takes the top max_detections of all classes' survivors.
 //   1. key[n] = score>thr ? (score_bits << 32 | ~n) : 0      (positive floats order as integers)
 //   2. bitonic sort, descending: score desc, equal scores -> lower anchor index first
 //   3. greedy NMS over the sorted candidates in chunks of 1024: a candidate dies when its IoU
@@ -72,7 +73,6 @@ __device__ __forceinline__ float iou_box(const f32x4 p, const f32x4 q) {
 }
 
 #define FILTER_THREADS 1024
-#define FILTER_MAX_DET 256
 #define FILTER_LDS_KEYS 16384      // candidates sorted in LDS (128 KB); more than that fall back to the global-memory sort
 
 // 64-bit bitonic sort, descending, n a power of two, by the whole workgroup (keys in LDS or global memory)
@@ -91,6 +91,33 @@ __device__ __forceinline__ void bitonic_desc(uint64_t* keys, int n, int tid) {
     }
 }
 
+// rows of one image: detection i < nk is anchor anchor_of(i) with class label_of(i); the rest of the max_det rows are -1
+template <class FA, class FL>
+__device__ __forceinline__ void filter_emit(const FilterArgs& a, int b, int nk, int tid, FA anchor_of, FL label_of) {
+  const f32x4* boxes = reinterpret_cast<const f32x4*>(a.boxes) + (int64_t)b * a.N;
+  if (tid == 0) a.det_count[b] = nk;
+  for (int i = tid; i < a.max_det; i += FILTER_THREADS) {
+    const bool ok = i < nk;
+    const int n = ok ? anchor_of(i) : 0, label = ok ? label_of(i) : 0;
+    const int64_t row = (int64_t)b * a.max_det + i;
+    const int64_t src = (int64_t)b * a.N + n;
+    if (a.det_index) a.det_index[row] = ok ? n : -1;
+    if (a.det_scores) a.det_scores[row] = ok ? a.scores[src * a.K + label] : -1.f;
+    if (a.det_labels) a.det_labels[row] = ok ? label : -1;
+    if (a.det_boxes) {
+      const f32x4 bb = ok ? boxes[n] : (f32x4){-1.f, -1.f, -1.f, -1.f};
+      *reinterpret_cast<f32x4*>(a.det_boxes + row * 4) = bb;
+    }
+    if (a.det_rotation) for (int c = 0; c < 3; c++) a.det_rotation[row * 3 + c] = ok ? a.rotation[src * 3 + c] : -1.f;
+    if (a.det_translation) for (int c = 0; c < 3; c++) a.det_translation[row * 3 + c] = ok ? a.translation[src * 3 + c] : -1.f;
+  }
+  if (a.det_hand)
+    for (int i = tid; i < a.max_det * 63; i += FILTER_THREADS) {
+      const int d = i / 63, c = i % 63;
+      a.det_hand[((int64_t)b * a.max_det + d) * 63 + c] = d < nk ? a.hand[((int64_t)b * a.N + anchor_of(d)) * 63 + c] : -1.f;
+    }
+}
+
 // Steps: (1) the candidates (score > thr) are COMPACTED into LDS - a trained network passes a handful of the 12 276 anchors,
 // and sorting all of them cost 0.9 ms per batch; (2) only the next power of two of their count is sorted (their order before
 // the sort does not matter: keys are unique, the sorted order is deterministic); (3) greedy NMS by ONE wave with ballots
@@ -102,8 +129,8 @@ __global__ __launch_bounds__(FILTER_THREADS) void filter_kernel(FilterArgs a) {
   __shared__ f32x4 kept_box[FILTER_MAX_DET];
   __shared__ int kept_idx[FILTER_MAX_DET];
   __shared__ int s_nkept, s_count;
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-  const float* scores = a.scores + (int64_t)b * a.N;
+  const int b = blockIdx.x, cls = blockIdx.y, K = a.K, tid = threadIdx.x, lane = tid & 63;
+  const float* scores = a.scores + (int64_t)b * a.N * K + cls;              // [N][K]: this class's column
   const f32x4* boxes = reinterpret_cast<const f32x4*>(a.boxes) + (int64_t)b * a.N;
   const int cap = min(a.npow2, FILTER_LDS_KEYS);
 
@@ -112,7 +139,7 @@ __global__ __launch_bounds__(FILTER_THREADS) void filter_kernel(FilterArgs a) {
   // (1) compaction: one LDS atomic per wave and pass
   for (int n0 = 0; n0 < a.N; n0 += FILTER_THREADS) {
     const int n = n0 + tid;
-    const float sc = n < a.N ? scores[n] : 0.f;
+    const float sc = n < a.N ? scores[(int64_t)n * K] : 0.f;
     const bool cand = n < a.N && sc > a.score_thr;
     const unsigned long long m = __ballot(cand);
     if (m) {
@@ -134,11 +161,11 @@ __global__ __launch_bounds__(FILTER_THREADS) void filter_kernel(FilterArgs a) {
     bitonic_desc(lkeys, np2, tid);
   } else {
     // more candidates than LDS holds (large images, untrained scores): all anchors, sorted in global memory
-    keys = a.keys + (int64_t)b * a.npow2; np2 = a.npow2;
+    keys = a.keys + (int64_t)(b * K + cls) * a.npow2; np2 = a.npow2;
     for (int n = tid; n < a.npow2; n += FILTER_THREADS) {
       uint64_t k = 0;
       if (n < a.N) {
-        const float sc = scores[n];
+        const float sc = scores[(int64_t)n * K];
         if (sc > a.score_thr) k = ((uint64_t)__float_as_uint(sc) << 32) | (uint32_t)(~(uint32_t)n);
       }
       keys[n] = k;
@@ -178,34 +205,55 @@ __global__ __launch_bounds__(FILTER_THREADS) void filter_kernel(FilterArgs a) {
   }
   __syncthreads();
   const int nk = s_nkept;
-  if (tid == 0) a.det_count[b] = nk;
-  for (int i = tid; i < a.max_det; i += FILTER_THREADS) {
-    const bool ok = i < nk;
-    const int n = ok ? kept_idx[i] : 0;
-    const int64_t row = (int64_t)b * a.max_det + i;
-    if (a.det_index) a.det_index[row] = ok ? n : -1;
-    if (a.det_scores) a.det_scores[row] = ok ? scores[n] : -1.f;
-    if (a.det_labels) a.det_labels[row] = ok ? 0 : -1;
-    if (a.det_boxes) {
-      const f32x4 bb = ok ? boxes[n] : (f32x4){-1.f, -1.f, -1.f, -1.f};
-      *reinterpret_cast<f32x4*>(a.det_boxes + row * 4) = bb;
-    }
-    const int64_t src = (int64_t)b * a.N + n;
-    if (a.det_rotation) for (int c = 0; c < 3; c++) a.det_rotation[row * 3 + c] = ok ? a.rotation[src * 3 + c] : -1.f;
-    if (a.det_translation) for (int c = 0; c < 3; c++) a.det_translation[row * 3 + c] = ok ? a.translation[src * 3 + c] : -1.f;
+  if (K > 1) {       // one of several classes: the survivors go to filter_merge_kernel (top-k over all classes)
+    for (int i = tid; i < nk; i += FILTER_THREADS) a.part_idx[(int64_t)(b * K + cls) * a.max_det + i] = kept_idx[i];
+    if (tid == 0) a.part_cnt[b * K + cls] = nk;
+    return;
   }
-  if (a.det_hand)
-    for (int i = tid; i < a.max_det * 63; i += FILTER_THREADS) {
-      const int d = i / 63, c = i % 63;
-      a.det_hand[((int64_t)b * a.max_det + d) * 63 + c] = d < nk ? a.hand[((int64_t)b * a.N + kept_idx[d]) * 63 + c] : -1.f;
+  filter_emit(a, b, nk, tid, [&](int i) { return kept_idx[i]; }, [&](int) { return 0; });
+}
+
+// num_classes > 1 (layers.py:347-380): the (anchor, class) pairs every class kept, concatenated class by class, then
+// tf.nn.top_k over their scores - descending, ties to the earlier pair - and the first max_detections rows.  One workgroup
+// per image sorts at most K * max_det <= 16 128 keys (score bits | ~position in the concatenation) in LDS.
+__global__ __launch_bounds__(FILTER_THREADS) void filter_merge_kernel(FilterArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint64_t lkeys[];
+  const int b = blockIdx.x, tid = threadIdx.x, K = a.K, total = K * a.max_det;
+  int np2 = 64;
+  while (np2 < total) np2 <<= 1;
+  HEP_POISON(lkeys, (size_t)np2 * 8);
+  __shared__ int s_total;
+  if (tid == 0) { int t = 0; for (int c = 0; c < K; c++) t += a.part_cnt[b * K + c]; s_total = t; }
+  for (int p = tid; p < np2; p += FILTER_THREADS) {
+    uint64_t key = 0;
+    if (p < total) {
+      const int c = p / a.max_det, i = p - c * a.max_det;
+      if (i < a.part_cnt[b * K + c]) {
+        const int n = a.part_idx[(int64_t)(b * K + c) * a.max_det + i];
+        key = ((uint64_t)__float_as_uint(a.scores[((int64_t)b * a.N + n) * K + c]) << 32) | (uint32_t)(~(uint32_t)p);
+      }
     }
+    lkeys[p] = key;
+  }
+  __syncthreads();
+  bitonic_desc(lkeys, np2, tid);
+  const int nk = min(s_total, a.max_det);
+  auto pos = [&](int i) { return (int)(~(uint32_t)lkeys[i]); };
+  filter_emit(a, b, nk, tid, [&](int i) { const int p = pos(i), c = p / a.max_det; return a.part_idx[(int64_t)(b * K + c) * a.max_det + (p - c * a.max_det)]; },
+              [&](int i) { return pos(i) / a.max_det; });
 }
 int filter_prepare(void) {
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(filter_merge_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, FILTER_LDS_KEYS * 8) != hipSuccess) return -1;
   return hipFuncSetAttribute(reinterpret_cast<const void*>(filter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, FILTER_LDS_KEYS * 8) == hipSuccess ? 0 : -1;
 }
 void launch_filter(const FilterArgs& a, hipStream_t s) {
   const size_t lds = (size_t)std::min(a.npow2, FILTER_LDS_KEYS) * 8;
-  hipLaunchKernelGGL(filter_kernel, dim3(a.B), dim3(FILTER_THREADS), lds, s, a);
+  hipLaunchKernelGGL(filter_kernel, dim3(a.B, a.K), dim3(FILTER_THREADS), lds, s, a);
+  if (a.K > 1) {
+    int np2 = 64;
+    while (np2 < a.K * a.max_det) np2 <<= 1;
+    hipLaunchKernelGGL(filter_merge_kernel, dim3(a.B), dim3(FILTER_THREADS), (size_t)np2 * 8, s, a);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------

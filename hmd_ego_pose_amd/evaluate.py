@@ -281,7 +281,11 @@ def evaluate(dataset: LinemodFolder, model, image_size: int, score_threshold: fl
     fp, tp, scores = [], [], []
     pairs = []                      # (rvec_gt, t_gt, rvec_pr, t_pr, drill_tip) of every correct 2D detection
     pair_cam, hand_err = [], []     # its camera matrix; mean joint distance in mm where the dataset carries hand joints
-    for i, (boxes, sc, _labels, rots, trans, hands) in enumerate(all_det):
+    for i, (boxes, sc, labels, rots, trans, hands) in enumerate(all_det):
+        # eval/common.py:603-611: detections are split by label and only the generator's labels are evaluated; the object
+        # folders of the reference hold ONE object (label 0), so rows a many-class model labels otherwise are dropped
+        own = labels == 0
+        boxes, sc, rots, trans, hands = boxes[own], sc[own], rots[own], trans[own], hands[own]
         ann = dataset.annotations[i]
         detected = False
         for d in range(boxes.shape[0]):

@@ -51,6 +51,8 @@ class Session:
                                                        self.device.index or 0, flags, ctypes.byref(h)))
         self.handle = h.value
         self.num_anchors = _capi.lib().hep_num_anchors(self.handle)
+        self.num_classes = _capi.lib().hep_num_classes(self.handle)      # read from the classifier header of the weights
+        self.out_width = tuple(self.num_classes if i == 1 else k for i, k in enumerate(OUT_WIDTH))
         self.lane_batch = max_batch      # frames per launch (the batch is one lane unless HEP_LANES says otherwise)
         if os.environ.get("HEP_LANES"):
             lanes = max(1, min(int(os.environ["HEP_LANES"]), max_batch, 16))
@@ -81,7 +83,7 @@ class Session:
             raise ValueError(f"expected a float32 ROCm tensor [B,3,{self.size},{self.size}], got {tuple(x.shape)} {x.dtype} on {x.device}")
         B = x.shape[0]
         N = self.num_anchors
-        outs = [torch.empty((B, N, k), dtype=torch.float32, device=x.device) for k in OUT_WIDTH]
+        outs = [torch.empty((B, N, k), dtype=torch.float32, device=x.device) for k in self.out_width]
         feats = [torch.empty((B, self.fpn_w, s, s), dtype=torch.float32, device=x.device) for s in self.levels] if want_features else None
         strides = (ctypes.c_int64 * 4)(*x.stride())
         stream = torch.cuda.current_stream(x.device).cuda_stream
@@ -97,7 +99,7 @@ class Session:
             def __init__(self, ptr, shape):
                 self.__cuda_array_interface__ = {"shape": shape, "typestr": "<f4", "data": (ptr, False), "version": 2}
         views = []
-        for i, k in enumerate(OUT_WIDTH):
+        for i, k in enumerate(self.out_width):
             p = ctypes.c_void_p()
             _capi.check(_capi.lib().hep_output_device(self.handle, 5 + i, ctypes.byref(p)))
             views.append(torch.as_tensor(_Buf(p.value, (self.max_batch, self.num_anchors, k)), device=self.device))
@@ -240,7 +242,7 @@ def _forward_flat(x, handle):
 def _(x, handle):
     s = _session(handle)
     B = x.shape[0]
-    return [x.new_empty((B, s.fpn_w, l, l)) for l in s.levels] + [x.new_empty((B, s.num_anchors, k)) for k in OUT_WIDTH]
+    return [x.new_empty((B, s.fpn_w, l, l)) for l in s.levels] + [x.new_empty((B, s.num_anchors, k)) for k in s.out_width]
 
 
 @torch.library.custom_op("hep::decode", mutates_args=())
@@ -323,7 +325,7 @@ class HMDEgoPose(nn.Module):
         if load_weights:
             raise ValueError("load_weights=True would download ImageNet weights; load a checkpoint with load_state_dict instead")
         self.compound_coef = int(compound_coef)
-        self.num_classes = num_classes
+        self.num_classes = int(num_classes)
         self.onnx_export = onnx_export
         self.input_sizes = list(input_sizes)
         self.precision = precision
@@ -337,7 +339,7 @@ class HMDEgoPose(nn.Module):
     def reset_parameters(self, seed: int = 0):
         from .weights import seeded_state_dict
         with torch.no_grad():
-            for k, v in seeded_state_dict(self.compound_coef, seed).items():
+            for k, v in seeded_state_dict(self.compound_coef, seed, num_classes=self.num_classes).items():
                 self.state_dict()[k].copy_(v)
 
     def invalidate(self):

@@ -30,7 +30,6 @@ from typing import Dict, Iterator, List, Optional
 import torch
 
 from . import _capi
-from .arch import OUT_WIDTH
 from .model import Session
 
 

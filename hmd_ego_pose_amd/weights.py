@@ -72,7 +72,7 @@ def _conv_role(key: str) -> str:
     return "lateral"
 
 
-def seeded_state_dict(phi: int, seed: int = 0, gain: float = 1.0) -> "OrderedDict[str, torch.Tensor]":
+def seeded_state_dict(phi: int, seed: int = 0, gain: float = 1.0, num_classes: int = 1) -> "OrderedDict[str, torch.Tensor]":
     """Deterministic synthetic weights (no checkpoint ships with the reference).
 
     Every tensor gets its own ``numpy`` PCG64 stream keyed by (seed, crc32(key)), so
@@ -83,7 +83,7 @@ def seeded_state_dict(phi: int, seed: int = 0, gain: float = 1.0) -> "OrderedDic
     BiFPN fusion weights ~ U(-0.5, 2) (negative ones hit the ReLU).
     """
     out: "OrderedDict[str, torch.Tensor]" = OrderedDict()
-    for key, shape in param_spec(phi):
+    for key, shape in param_spec(phi, num_classes):   # (num_classes only changes the classifier header's two tensors)
         rng = np.random.Generator(np.random.PCG64([seed, zlib.crc32(key.encode())]))
         kind = _kind(key)
         if kind == "count":

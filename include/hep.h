@@ -93,6 +93,9 @@ void hep_destroy(hep_handle* h);
 
 /* Geometry. */
 int hep_num_anchors(const hep_handle* h);                       /* N = 9 * sum(level cells)          */
+/* Classes of the classifier, read from the weights: its header holds 9 * num_classes channels (efficientdet/model.py:393;
+ * backbone.py:14 `num_classes`, 1 at every reference call site).  1..63. */
+int hep_num_classes(const hep_handle* h);
 int hep_output_shape(const hep_handle* h, int index, int batch, int64_t dims[4], int* ndim);
 /* The handle's OWN device buffer of head output `index` (HEP_OUT_REGRESSION .. HEP_OUT_HAND), fp32 [max_batch, N, K]:
  * where hep_run_device leaves its results when outs == NULL.  Valid until hep_destroy; rewritten by the next forward on
@@ -103,7 +106,7 @@ int hep_output_device(const hep_handle* h, int index, float** ptr);
 /* Session.Run replacement: host buffers in, host buffers out, synchronous.
  * input: fp32 NCHW [batch,3,S,S], already normalised.  feats may be NULL (or hold NULLs):
  * feature maps are then not exported.  Outputs are caller-allocated, fp32:
- * feats[l] NCHW [batch,W,s_l,s_l]; regression [batch,N,4]; classification [batch,N,1] (post-sigmoid);
+ * feats[l] NCHW [batch,W,s_l,s_l]; regression [batch,N,4]; classification [batch,N,num_classes] (post-sigmoid);
  * rotation [batch,N,3]; translation_raw [batch,N,3]; hand [batch,N,63]. */
 int hep_run(hep_handle* h, const float* input_nchw, int batch, float* const feats[5],
             float* regression, float* classification, float* rotation, float* translation_raw, float* hand);
@@ -134,7 +137,11 @@ int hep_decode_device(hep_handle* h, const float* regression, const float* trans
 
 /* Detection filter per image: score > score_threshold -> greedy NMS (IoU strictly greater than
  * nms_threshold suppresses; candidates by descending score, ties by lower anchor index) -> first
- * max_detections survivors -> rows padded with -1.  Unlike the reference (which returns only the
+ * max_detections survivors -> rows padded with -1.  classification is [batch,N,num_classes]; with more than one class
+ * the filter is class-specific (layers.py:347-358, the reference's default and the only mode it constructs,
+ * train.py:78-81): every class is thresholded and suppressed on its own, the (anchor, class) pairs of all classes are
+ * concatenated class by class and the max_detections best scores are kept (ties: the earlier pair); det_labels holds
+ * the class.  Unlike the reference (which returns only the
  * last batch item, layers.py:466-482) every image gets its rows.
  * det_boxes [batch,M,4], det_scores [batch,M], det_labels [batch,M] (int32), det_rotation [batch,M,3],
  * det_translation [batch,M,3], det_hand [batch,M,63], det_index [batch,M] (int32 anchor index),

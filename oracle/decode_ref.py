@@ -129,16 +129,29 @@ def nms_greedy(boxes: np.ndarray, scores: np.ndarray, max_out: int, iou_thr: flo
 
 
 def filter_detections(boxes, classification, rotation, translation, hand,
-                      score_threshold=0.5, max_detections=100, nms_threshold=0.5):
-    """filter_detections, layers.py:264-400, one image, num_classes == 1: indices with
-    score > threshold -> NMS -> top_k (already score-sorted, ties lower index) -> gather ->
-    pad with -1 to max_detections rows.  Returns (boxes[M,4], scores[M], labels[M] int32,
-    rotation[M,3], translation[M,3], hand[M,63], anchor_index[M] int32 (-1 padded))."""
-    s = classification[:, 0].astype(np.float32)
-    cand = np.nonzero(s > np.float32(score_threshold))[0]
-    kept = cand[nms_greedy(boxes[cand], s[cand], max_detections, nms_threshold)] if len(cand) else cand
-    order = np.lexsort((np.arange(len(kept)), -s[kept].astype(np.float64)))[:max_detections]
-    idx = kept[order]
+                      score_threshold=0.5, max_detections=100, nms_threshold=0.5, class_specific_filter=True):
+    """filter_detections, layers.py:264-400, one image.  Per class c (class_specific_filter, :347-354): anchors with
+    classification[:, c] > threshold -> NMS (at most max_detections survivors, in NMS order) -> (anchor, c) pairs; the
+    pairs of all classes concatenated class by class (:358).  Otherwise (:359-362) one pass over the best class of every
+    anchor (max / first argmax).  Then top_k over the pairs' scores (:365-367; ties: the earlier pair) -> gather -> pad with
+    -1 to max_detections rows.  Returns (boxes[M,4], scores[M], labels[M] int32, rotation[M,3], translation[M,3],
+    hand[M,63], anchor_index[M] int32 (-1 padded)).  With one class both modes are the same pass."""
+    cls = np.asarray(classification, dtype=np.float32)
+    cls = cls.reshape(cls.shape[0], -1)
+
+    def one_pass(s, labels):            # _filter_detections, layers.py:305-345
+        cand = np.nonzero(s > np.float32(score_threshold))[0]
+        kept = cand[nms_greedy(boxes[cand], s[cand], max_detections, nms_threshold)] if len(cand) else cand
+        return kept.astype(np.int64), labels[kept].astype(np.int64)
+
+    if class_specific_filter:
+        parts = [one_pass(cls[:, c], np.full(cls.shape[0], c, np.int64)) for c in range(cls.shape[1])]
+        anchors, labels = np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
+    else:
+        anchors, labels = one_pass(cls.max(axis=1), cls.argmax(axis=1))
+    s = cls[anchors, labels]
+    order = np.lexsort((np.arange(len(s)), -s.astype(np.float64)))[:max_detections]
+    idx, lab = anchors[order], labels[order]
     n = len(idx)
 
     def pad(a, w=None):
@@ -147,7 +160,7 @@ def filter_detections(boxes, classification, rotation, translation, hand,
         out[:n] = a
         return out
 
-    return (pad(boxes[idx].astype(np.float32), 4), pad(s[idx]), pad(np.zeros(n, np.int32)),
+    return (pad(boxes[idx].astype(np.float32), 4), pad(s[order]), pad(lab.astype(np.int32)),
             pad(rotation[idx].astype(np.float32), 3), pad(translation[idx].astype(np.float32), 3),
             pad(hand[idx].astype(np.float32), hand.shape[1]), pad(idx.astype(np.int32)))
 

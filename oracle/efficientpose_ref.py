@@ -177,6 +177,11 @@ def bifpn_cell(sd, p: str, feats, first: bool, attention: bool):
     return p3_out, p4_out, p5_out, p6_out, p7_out
 
 
+def num_classes(sd) -> int:
+    """Classes of the classifier: its header has num_anchors * num_classes channels (efficientdet/model.py:393)."""
+    return int(sd["classifier.header.pointwise_conv.conv.weight"].shape[0]) // NUM_ANCHORS
+
+
 def head(sd, name: str, depth: int, feats, headers: List[Tuple[str, int]], sigmoid=False) -> torch.Tensor:
     """Regressor/Classifier.forward efficientdet/model.py:361-417 and RotationNet/TranslationNet/
     HandNet.forward hmdegopose/model.py:55-90,127-156,191-228 with num_iteration_steps == 0:
@@ -198,8 +203,9 @@ def head(sd, name: str, depth: int, feats, headers: List[Tuple[str, int]], sigmo
 @torch.no_grad()
 def forward(sd: Mapping[str, torch.Tensor], x: torch.Tensor, phi: int, trace: Dict[str, torch.Tensor] | None = None):
     """HMDEgoPose.forward, backbone.py:104-125.  x: fp32 [B,3,S,S] (any strides).
-    Returns (features(5), regression[B,N,4], classification[B,N,1] (post-sigmoid),
-    rotation[B,N,3], translation_raw[B,N,3], hand[B,N,63])."""
+    Returns (features(5), regression[B,N,4], classification[B,N,num_classes] (post-sigmoid),
+    rotation[B,N,3], translation_raw[B,N,3], hand[B,N,63]).  num_classes is what the classifier's header holds
+    (efficientdet/model.py:393: num_anchors * num_classes output channels, reshaped per anchor at :406-408)."""
     attention = phi < 6
     feats = backbone(sd, phi, x.float(), trace)
     if trace is not None:
@@ -212,7 +218,7 @@ def forward(sd: Mapping[str, torch.Tensor], x: torch.Tensor, phi: int, trace: Di
     d = _HEAD_DEPTH[phi]
     A = NUM_ANCHORS
     regression = head(sd, "regressor", d, feats, [("header", 4)])
-    classification = head(sd, "classifier", d, feats, [("header", 1)], sigmoid=True)
+    classification = head(sd, "classifier", d, feats, [("header", num_classes(sd))], sigmoid=True)
     rotation = head(sd, "rotation_net", d, feats, [("initial_rotation", 3)])
     translation = head(sd, "translation_net", d, feats, [("initial_translation_xy", 2), ("initial_translation_z", 1)])
     hand = head(sd, "hand_net", d, feats, [("initial_hand_coords", 63)])
@@ -411,7 +417,7 @@ def emulated_stages(sd: Mapping[str, torch.Tensor], phi: int, q_act=q_bf16, q_w=
     @torch.no_grad()
     def heads(feats):
         return (_head_emu(E, sd, "regressor", d, feats, [("header", 4)]),
-                _head_emu(E, sd, "classifier", d, feats, [("header", 1)], sigmoid=True),
+                _head_emu(E, sd, "classifier", d, feats, [("header", num_classes(sd))], sigmoid=True),
                 _head_emu(E, sd, "rotation_net", d, feats, [("initial_rotation", 3)]),
                 _head_emu(E, sd, "translation_net", d, feats, [("initial_translation_xy", 2), ("initial_translation_z", 1)]),
                 _head_emu(E, sd, "hand_net", d, feats, [("initial_hand_coords", 63)]))

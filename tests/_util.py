@@ -15,6 +15,9 @@ CASES = {  # tag -> (phi, size, batch, seed, input kind)
     "phi0_s256_b16_seed0": (0, 256, 16, 0, "normal"),
     "phi3_s512_b8_seed0": (3, 512, 8, 0, "normal"),
 }
+CLASS_CASES = {  # tag -> (phi, size, batch, seed, input kind, num_classes): the classifier header with more than one class
+    "phi0_s256_b2_seed0_k3": (0, 256, 2, 0, "normal", 3),
+}
 CAMS = np.array([[480, 480, 128, 128, 1000, 1.0],
                  [572.4114, 573.57043, 325.2611, 242.04899, 1000, 0.8]], dtype=np.float32)
 

@@ -91,14 +91,14 @@ def main():
     # ---- 2. network forward: reference module on seeded weights ---------------------------
     cams = np.array([[480, 480, 128, 128, 1000, 1.0],
                      [572.4114, 573.57043, 325.2611, 242.04899, 1000, 0.8]], dtype=np.float32)
-    from tests._util import CASES, strides_for      # one table of cases / slice strides for this script and the tests
-    for (phi, size, batch, seed, kind) in CASES.values():
-        tag = f"phi{phi}_s{size}_b{batch}_seed{seed}"
-        model = HMDEgoPose({"iter": 0}, num_classes=1, compound_coef=phi, onnx_export=True, input_sizes=[size] * 9).eval()
+    from tests._util import CASES, CLASS_CASES, strides_for      # one table of cases / slice strides for this script and the tests
+    for tag, (phi, size, batch, seed, kind, classes) in [(t, c + (1,)) for t, c in CASES.items()] + list(CLASS_CASES.items()):
+        assert tag == f"phi{phi}_s{size}_b{batch}_seed{seed}" + (f"_k{classes}" if classes != 1 else "")
+        model = HMDEgoPose({"iter": 0}, num_classes=classes, compound_coef=phi, onnx_export=True, input_sizes=[size] * 9).eval()
         ref_keys = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
-        assert ref_keys == param_spec(phi), "arch.param_spec drifted from the reference state_dict"
-        meta[f"keys_phi{phi}_sha256"] = hashlib.sha256(repr(ref_keys).encode()).hexdigest()
-        sd = seeded_state_dict(phi, seed)
+        assert ref_keys == param_spec(phi, classes), "arch.param_spec drifted from the reference state_dict"
+        meta[f"keys_phi{phi}" + (f"_k{classes}" if classes != 1 else "") + "_sha256"] = hashlib.sha256(repr(ref_keys).encode()).hexdigest()
+        sd = seeded_state_dict(phi, seed, num_classes=classes)
         model.load_state_dict(sd, strict=True)
         x = torch.from_numpy(seeded_input((batch, 3, size, size), seed, kind))
         # hooks: stage boundaries to localise bugs (stem, every MBConv, every BiFPN cell)
@@ -123,10 +123,11 @@ def main():
             h.remove()
         out, info = {}, {}
         named = {"regression": reg, "classification": cls, "rotation": rot, "translation_raw": trn, "hand": hand}
-        for l, f in enumerate(feats):
-            named[f"feat{l + 3}"] = f.permute(0, 2, 3, 1)          # stored NHWC
-        for k, v in trace.items():
-            named["trace_" + k] = v.permute(0, 2, 3, 1)
+        if classes == 1:     # (a class case shares every weight but the classifier header with its one-class twin: heads only)
+            for l, f in enumerate(feats):
+                named[f"feat{l + 3}"] = f.permute(0, 2, 3, 1)          # stored NHWC
+            for k, v in trace.items():
+                named["trace_" + k] = v.permute(0, 2, 3, 1)
         for k, v in named.items():
             info[k], out[k] = digest(v.numpy(), strides_for(size, k, batch))
         # decode through the reference's own format_bboxes / format_translation

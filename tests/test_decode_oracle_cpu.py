@@ -58,6 +58,37 @@ def test_nms_known_answer_and_padding():
     assert out3[6].tolist() == [-1, -1, -1] and np.all(out3[0] == -1)
 
 
+def test_filter_with_several_classes_known_answer():
+    """layers.py:347-380 worked by hand.  Boxes A, B overlap (IoU 81 / 119 = 0.68), C is far away.
+    class 0: A .9, B .8, C .7 -> A kept, B suppressed by A, C kept;  class 1: B .95, A .6, C .2 -> B kept, A suppressed by B.
+    Pairs class by class: (A,0) (C,0) (B,1) with scores .9 .7 .95 -> top_k: (B,1) (A,0) (C,0).
+    Not class-specific (:359-362): best class per anchor: A .9 / 0, B .95 / 1, C .7 / 0 -> B kept, A suppressed, C kept."""
+    b = np.array([[0, 0, 10, 10], [1, 1, 11, 11], [50, 50, 60, 60]], np.float32)
+    cls = np.array([[.9, .6], [.8, .95], [.7, .2]], np.float32)
+    rot = np.arange(9, dtype=np.float32).reshape(3, 3)
+    hand = np.tile(np.arange(3, dtype=np.float32)[:, None], (1, 63))
+    boxes, scores, labels, r, t, h, idx = D.filter_detections(b, cls, rot, -rot, hand, score_threshold=0.5, max_detections=5)
+    assert idx.tolist() == [1, 0, 2, -1, -1] and labels.tolist() == [1, 0, 0, -1, -1]
+    assert scores.tolist() == [np.float32(.95), np.float32(.9), np.float32(.7), -1, -1]
+    assert np.array_equal(boxes[0], b[1]) and np.array_equal(r[1], rot[0]) and h[2, 5] == 2 and np.all(t[3:] == -1)
+    out = D.filter_detections(b, cls, rot, -rot, hand, score_threshold=0.5, max_detections=5, class_specific_filter=False)
+    assert out[6].tolist() == [1, 2, -1, -1, -1] and out[2].tolist() == [1, 0, -1, -1, -1]
+    # the same anchor may come out once per class; max_detections caps every class's pass AND the final top_k
+    far = np.array([[0, 0, 10, 10], [20, 20, 30, 30], [50, 50, 60, 60]], np.float32)
+    out = D.filter_detections(far, cls, rot, -rot, hand, score_threshold=0.5, max_detections=2)
+    assert out[6].tolist() == [1, 0] and out[2].tolist() == [1, 0]            # class 0 keeps (A, B), class 1 keeps (B, A): .95, .9
+    out = D.filter_detections(far, cls, rot, -rot, hand, score_threshold=0.1, max_detections=6)
+    assert out[6].tolist() == [1, 0, 1, 2, 0, 2] and out[2].tolist() == [1, 0, 0, 0, 1, 1]
+    # equal scores: top_k keeps the earlier pair of the class-by-class concatenation
+    tie = np.array([[.7, .7], [.7, .2], [.2, .7]], np.float32)
+    out = D.filter_detections(far, tie, rot, -rot, hand, score_threshold=0.5, max_detections=4)
+    assert out[6].tolist() == [0, 1, 0, 2] and out[2].tolist() == [0, 0, 1, 1]
+    # one class: both modes are the same pass
+    one = cls[:, :1]
+    for a, c in zip(D.filter_detections(b, one, rot, -rot, hand), D.filter_detections(b, one, rot, -rot, hand, class_specific_filter=False)):
+        assert np.array_equal(a, c)
+
+
 def test_post_filter_matches_evaluate_loop():
     b, s = _boxes()
     rot = np.ones((8, 3), np.float32) * 0.5

@@ -27,7 +27,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests._util import CAMS, CASES, check_digest, golden_case, seeded_input, strides_for
+from tests._util import CAMS, CASES, CLASS_CASES, check_digest, golden_case, seeded_input, strides_for
 
 pytestmark = pytest.mark.gpu
 
@@ -411,6 +411,91 @@ def test_filter_with_more_candidates_than_lds_holds(api):
                                 score_threshold=thr, max_detections=100, nms_threshold=0.5)
         assert det["index"][0].cpu().numpy().tolist() == o[6].tolist(), thr
     s.close()
+
+
+@pytest.mark.parametrize("tag", list(CLASS_CASES))
+def test_classifier_with_several_classes(api, tag, monkeypatch):
+    """num_classes > 1 (backbone.py:14; efficientdet/model.py:385-410; hmdegopose/layers.py:347-380): the session reads the
+    class count from the classifier header of the weights, the classification output is [B, N, num_classes], and the filter
+    is the reference's class-specific one.  fp32 within 1e-3 of the oracle and of the golden vectors of the real reference
+    module built with that num_classes; bf16 teacher-free but close; the depth-first head kernel bit-identical; the module
+    drop-in returns the class labels."""
+    from hmd_ego_pose_amd import HMDEgoPose, TrainModelWithLoss
+    D = api["D"]
+    phi, size, batch, seed, kind, classes = CLASS_CASES[tag]
+    sd = api["sd"](phi, seed, num_classes=classes)
+    x = torch.from_numpy(seeded_input((batch, 3, size, size), seed, kind))
+    ref = api["R"].forward(sd, x, phi)
+    s = api["Session"](sd, phi, size, batch, "fp32")
+    assert s.num_classes == classes and s.out_width == (4, classes, 3, 3, 63)
+    out = s.forward(x.cuda())
+    got = {k: v.float().cpu() for k, v in _named(*out).items()}
+    assert tuple(got["classification"].shape) == (batch, s.num_anchors, classes)
+    for k, w in _named(*ref).items():
+        assert (got[k] - w).abs().max().item() <= 1e-3, k
+    info, gold = golden_case(tag)
+    for k in ("regression", "classification", "rotation", "translation_raw", "hand"):
+        check_digest(k, got[k].numpy(), info[k], gold[k], strides_for(size, k, batch), atol=1e-3, rtol=1e-4)
+    views = s.output_views()
+    assert tuple(views[1].shape) == (batch, s.num_anchors, classes) and torch.equal(views[1][:batch], out[2])
+    # the filter on the network's own outputs, bit for bit (seeded scores: about half of all (anchor, class) pairs pass 0.5)
+    _, reg, cls, rot, trn, hand = out
+    cam = torch.from_numpy(np.repeat(CAMS[:1], batch, 0)).cuda()
+    boxes, trans = s.decode(reg, trn, cam)
+    for thr, M in ((0.5, 100), (0.7, 7), (2.0, 5)):
+        det = s.filter(boxes, cls, rot, trans, hand, score_threshold=thr, nms_threshold=0.5, max_detections=M)
+        for i in range(batch):
+            o = D.filter_detections(boxes[i].cpu().numpy(), cls[i].cpu().numpy(), rot[i].cpu().numpy(), trans[i].cpu().numpy(),
+                                    hand[i].cpu().numpy(), score_threshold=thr, max_detections=M, nms_threshold=0.5)
+            for key, want in zip(("boxes", "scores", "labels", "rotation", "translation", "hand", "index"), o):
+                assert np.array_equal(det[key][i].cpu().numpy(), want), (thr, M, i, key)
+            assert int(det["count"][i]) == int((o[6] >= 0).sum())
+    # bf16 session of the same weights: same shapes, finite, the classes in the same order
+    sb = api["Session"](sd, phi, size, batch, "bf16")
+    cb = sb.forward(x.cuda())[2].float().cpu()
+    assert cb.shape == got["classification"].shape and torch.isfinite(cb).all() and (cb - got["classification"]).abs().mean().item() < 0.05
+    monkeypatch.setenv("HEP_HEADS_FUSED", "1")
+    sf = api["Session"](sd, phi, size, batch, "bf16")
+    assert any(y == "heads_kernel" for _, y in _plan_syms(sf, batch))
+    assert torch.equal(sf.forward(x.cuda())[2].float().cpu(), cb)
+    monkeypatch.delenv("HEP_HEADS_FUSED")
+    for t in (s, sb, sf):
+        t.close()
+    # module drop-in: same constructor argument as the reference
+    m = HMDEgoPose({"iter": 0}, num_classes=classes, compound_coef=phi, onnx_export=True, input_sizes=[size] * 9)
+    m.load_state_dict(sd, strict=True)
+    m = m.to("cuda").eval()
+    mo = m(x.cuda())
+    assert tuple(mo[2].shape) == (batch, 12276, classes) and (mo[2].cpu() - ref[2]).abs().max().item() <= 1e-3
+    last = TrainModelWithLoss(m).eval()(x.cuda(), cam.cpu(), params={"img_size": (size, size)})
+    gb, gt = m.session(size, batch, torch.device("cuda", 0)).decode(mo[1], mo[4], cam)
+    sel = D.filter_detections(gb[-1].cpu().numpy(), mo[2][-1].cpu().numpy(), mo[3][-1].cpu().numpy(), gt[-1].cpu().numpy(), mo[5][-1].cpu().numpy())
+    for g, w in zip(last, sel[:6]):
+        assert np.array_equal(g.numpy(), w)
+    assert set(np.unique(sel[2]).tolist()) - {-1} == set(range(classes))      # (every class is among the 100 rows: the labels are exercised)
+
+
+def test_filter_with_several_classes_fuzz(api):
+    """The class-specific filter against the oracle on hostile inputs: tied scores across and inside classes, more candidates
+    per class than LDS holds (global-memory sort), max_detections at the cap, a class with no candidate."""
+    D = api["D"]
+    for classes, size, M, thr in ((2, 512, 100, 0.1), (5, 256, 256, 0.3), (63, 256, 256, 0.9), (4, 256, 9, 0.5)):
+        sd = api["sd"](0, 0, num_classes=classes)
+        s = api["Session"](sd, 0, size, 2, "fp32")
+        N = s.num_anchors
+        rng = np.random.Generator(np.random.PCG64([classes, size]))
+        cxy = rng.uniform(20, size - 20, (2, N, 2)); wh = rng.uniform(4, 60, (2, N, 2))
+        boxes = np.concatenate([cxy - wh / 2, cxy + wh / 2], axis=2).astype(np.float32)
+        cls = (rng.integers(0, 64, (2, N, classes)) / 64.0).astype(np.float32)          # 64 distinct scores: ties everywhere
+        cls[1, :, classes - 1] = 0.0                                                     # the last class of image 1 passes nothing
+        rot = rng.standard_normal((2, N, 3)).astype(np.float32); hand = rng.standard_normal((2, N, 63)).astype(np.float32)
+        t = lambda a: torch.from_numpy(a).cuda()
+        det = s.filter(t(boxes), t(cls), t(rot), t(-rot), t(hand), score_threshold=thr, nms_threshold=0.5, max_detections=M)
+        for i in range(2):
+            o = D.filter_detections(boxes[i], cls[i], rot[i], -rot[i], hand[i], score_threshold=thr, max_detections=M, nms_threshold=0.5)
+            for key, want in zip(("boxes", "scores", "labels", "rotation", "translation", "hand", "index"), o):
+                assert np.array_equal(det[key][i].cpu().numpy(), want), (classes, i, key)
+        s.close()
 
 
 def test_module_dropin_and_pipeline(api):
