@@ -662,7 +662,7 @@ int hep_debug_tensor_info(const hep_handle* h, int i, const char** name, int64_t
   if (!h || i < 0 || i >= (int)h->s.tensors.size()) return fail(HEP_ERR_INVALID, "bad tensor index");
   const TensorDesc& t = h->s.tensors[i];
   if (name) *name = t.name.c_str();
-  if (dims) { dims[0] = h->s.max_batch; dims[1] = t.H; dims[2] = t.W; dims[3] = t.C; }
+  if (dims) { dims[0] = h->s.max_batch; dims[1] = t.H; dims[2] = t.W; dims[3] = t.C_logical ? t.C_logical : t.C; }
   return 0;
 } HEP_CATCH_INT
 int hep_debug_tensor(hep_handle* h, const char* name, int batch, float* out, size_t capacity) try {
@@ -672,21 +672,35 @@ int hep_debug_tensor(hep_handle* h, const char* name, int batch, float* out, siz
   if (it == s.tensor_by_name.end()) return fail(HEP_ERR_INVALID, std::string("no stage tensor named '") + name + "'");
   if (batch < 1 || batch > s.max_batch) return fail(HEP_ERR_UNSUPPORTED, "batch outside 1..max_batch");
   const TensorDesc& t = s.tensors[it->second];
-  const size_t n = (size_t)batch * t.H * t.W * t.C;
+  const int C = t.C_logical ? t.C_logical : t.C;                     // (the allocation may be padded: NHWC rows are C apart all the same)
+  const size_t n = (size_t)batch * t.H * t.W * C;
   if (n > capacity) return fail(HEP_ERR_INVALID, "output buffer too small");
   std::lock_guard<std::mutex> lk(s.mu);
   HIPRET(hipSetDevice(s.device));
   HIPRET(hipDeviceSynchronize());
-  const size_t per = (size_t)t.H * t.W * t.C;
+  const bool f32 = t.f32 || s.dtype == HEP_F32;
+  const size_t per = (size_t)t.H * t.W * C, per_alloc = (size_t)t.H * t.W * t.C;
   for (int ln = 0; ln < s.lanes_for(batch); ln++) {
-    const size_t cnt = (size_t)s.lane_count(batch, ln) * per;
+    const int nb = s.lane_count(batch, ln);
     float* dst = out + (size_t)ln * s.lane_batch * per;
-    if (t.f32 || s.dtype == HEP_F32) { HIPRET(hipMemcpy(dst, s.tptr(it->second, ln), cnt * 4, hipMemcpyDeviceToHost)); }
+    const size_t cnt = (size_t)nb * (t.frag ? per_alloc : per);      // elements to fetch
+    std::vector<float> raw(cnt);
+    if (f32) { HIPRET(hipMemcpy(raw.data(), s.tptr(it->second, ln), cnt * 4, hipMemcpyDeviceToHost)); }
     else {
       std::vector<uint16_t> tmp(cnt);
       HIPRET(hipMemcpy(tmp.data(), s.tptr(it->second, ln), cnt * 2, hipMemcpyDeviceToHost));
-      for (size_t i = 0; i < cnt; i++) { uint32_t u = (uint32_t)tmp[i] << 16; memcpy(&dst[i], &u, 4); }
+      for (size_t i = 0; i < cnt; i++) { uint32_t u = (uint32_t)tmp[i] << 16; memcpy(&raw[i], &u, 4); }
     }
+    if (!t.frag) { memcpy(dst, raw.data(), cnt * 4); continue; }
+    // fragment order -> NHWC: row m = (image, pixel) of this lane, channel k lives in the 16-byte unit
+    // ((m / 16) * ksteps + k / KSTEP) * 64 + (k % KSTEP) / KLANE * 16 + m % 16 at element k % KLANE (k_mbf.hip ostore)
+    const int kstep = f32 ? 16 : 32, klane = f32 ? 4 : 8, kst = (C + kstep - 1) / kstep;
+    const size_t rows = (size_t)nb * t.H * t.W;
+    for (size_t m = 0; m < rows; m++)
+      for (int k = 0; k < C; k++) {
+        const size_t unit = ((m >> 4) * kst + k / kstep) * 64 + (size_t)((k % kstep) / klane) * 16 + (m & 15);
+        dst[m * C + k] = raw[unit * klane + k % klane];
+      }
   }
   return 0;
 } HEP_CATCH_INT

@@ -41,6 +41,8 @@ struct TensorDesc {
   int H, W, C; bool f32;            // NHWC; f32 forces fp32 storage (head outputs, SE buffers)
   size_t bytes_per_image; size_t offset;
   int first_op = -1, last_op = -1;
+  int C_logical = 0;                // channels the layer has when the allocation is padded (0: C); frag: stored in the project GEMM's fragment
+  bool frag = false;                // order (k_pw_impl.h FRAG: 16-byte units [m / 16][k-step][lane]) instead of NHWC - hep_debug_tensor undoes both
   bool external = false;            // lives in its own allocation (outputs)
   void* ext_ptr = nullptr;
 };

@@ -370,7 +370,7 @@ struct Planner {
           if (k < K) wfr[(((size_t)nt * kst + ks) * 64 + lane) * klane + e] = wf[(size_t)(nt * 16 + (lane & 15)) * K + k];
         }
         wref(op, F_PW_W, wb.put_typed(wfr));
-        s->ops[op].pw.frag = 1; s->ops[producer].mbf.out_frag = 1;
+        s->ops[op].pw.frag = 1; s->ops[producer].mbf.out_frag = 1; s->tensors[in_t].frag = true;
       } else wref(op, F_PW_W, wb.put_typed(wf));
     }
     wref(op, F_PW_B, wb.put_f32(bf));
@@ -541,6 +541,7 @@ struct Planner {
       for (int t = 0; t < b.k * b.k; t++) wdw[(size_t)t * b.cexp + c] = wd->data[(size_t)c * b.k * b.k + t] * bn1.scale[c];
     snprintf(nm, sizeof nm, "b%d.dw", i);
     const int dw_t = tensor(nm, Ho, Wo, (b.cexp + 31) & ~31);      // (room for the project GEMM's fragment order: K padded to whole k-steps)
+    s->tensors[dw_t].C_logical = b.cexp;
 
     // fused front (expand -> LDS -> depthwise, k_mbf.hip) whenever its LDS tiles fit; the expanded
     // tensor then never reaches HBM.  HEP_NO_MBF=1 forces the two-kernel path (A/B measurements).

@@ -256,7 +256,10 @@ def state_dict_from_onnx(path_or_bytes, phi: int) -> Dict[str, "np.ndarray"]:
     data = path_or_bytes if isinstance(path_or_bytes, (bytes, bytearray)) else open(path_or_bytes, "rb").read()
     init = read_initializers(data)
     named = strip_checkpoint_prefix(OrderedDict((k, torch.from_numpy(np.array(v))) for k, v in init.items()))
-    want = OrderedDict(param_spec(phi))
+    # num_classes is what the classifier header holds (9 * num_classes channels; it has no BatchNorm behind it, so it keeps its name in both kinds of export)
+    hdr = named.get("classifier.header.pointwise_conv.conv.weight")
+    classes = int(hdr.shape[0]) // 9 if hdr is not None and hdr.dim() == 4 and hdr.shape[0] % 9 == 0 and 9 <= hdr.shape[0] <= 9 * 63 else 1
+    want = OrderedDict(param_spec(phi, classes))
     missing = [k for k in want if k not in named and not k.endswith("num_batches_tracked")]
     wrong = [k for k in want if k in named and tuple(named[k].shape) != tuple(want[k])]
     if wrong:

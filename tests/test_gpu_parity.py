@@ -640,6 +640,39 @@ def test_bf16_plan_variants_are_bit_identical(api, phi, env, monkeypatch):
     s.close()
 
 
+@pytest.mark.parametrize("precision,phi,size,batch", [("bf16", 0, 256, 16), ("fp32", 0, 256, 16), ("bf16", 0, 256, 3), ("bf16", 3, 512, 2), ("fp32", 1, 384, 2)])
+def test_fragment_ordered_project_gemms_are_bit_identical(api, precision, phi, size, batch, monkeypatch):
+    """The split-K project GEMMs of the default plan read both operands in MFMA fragment order (k_pw_impl.h FRAG: the fused front
+    stores its depthwise output as [m / 16][k-step][lane] 16-byte units, the weights are packed the same way, K padded to whole
+    k-steps with zeros).  Only the memory order changes: every head output and every block output must equal the row-major plan
+    (HEP_PW_FRAG=0) bit for bit, and hep_debug_tensor must hand the fragment-ordered (and channel-padded) depthwise tensors back as
+    NHWC with their logical channel count."""
+    flags = api["capi"].FLAG_KEEP_INTERMEDIATES
+    sd = api["sd"](phi, 6)
+    x = torch.from_numpy(seeded_input((batch, 3, size, size), 31)).cuda()
+    s = api["Session"](sd, phi, size, batch, precision, flags=flags)
+    plan = _plan_syms(s, batch)
+    fr = [n for n, y in plan if y.startswith("pw_gemm_kernel<") and y.endswith(", true>")]
+    assert len(fr) >= (8 if batch == 16 else 1) and all(n.endswith(".project") for n in fr), plan
+    want = [t.clone() for t in s.forward(x)[1:]]
+    blocks = [int(n[1:n.index(".")]) for n in fr]
+    wdw = {i: s.stage(f"b{i}.dw", batch) for i in blocks}
+    wout = {i: s.stage(f"block{i}", batch) for i in blocks}
+    cexp = {i: sd[f"backbone_net.model._blocks.{i}._depthwise_conv.conv.weight"].shape[0] for i in blocks}
+    assert all(wdw[i].shape[-1] == cexp[i] for i in blocks), "a padded tensor must report its logical channel count"
+    s.close()
+    monkeypatch.setenv("HEP_PW_FRAG", "0")
+    s = api["Session"](sd, phi, size, batch, precision, flags=flags)
+    assert not any(y.endswith(", true>") for _, y in _plan_syms(s, batch))
+    got = s.forward(x)[1:]
+    for name, a, b in zip(("regression", "classification", "rotation", "translation_raw", "hand"), got, want):
+        assert torch.equal(a, b), f"{name}: max |diff| {(a - b).abs().max().item():.3e}"
+    for i in blocks:
+        assert torch.equal(s.stage(f"block{i}", batch), wout[i]), f"block{i}"
+        assert torch.equal(s.stage(f"b{i}.dw", batch), wdw[i]), f"b{i}.dw read back through the fragment order differs from the row-major tensor"
+    s.close()
+
+
 def test_nan_input_reaches_every_fp32_head_as_nan(api):
     """The fp32 activations use v_rcp_f32 + one Newton step behind a clamp of the denominator (hep_dev.h: rcp_newton): the clamp
     must let a NaN through (fminf(NaN, c) is c: a NaN logit once came out of the classification sigmoid as ~1e-38 and would
