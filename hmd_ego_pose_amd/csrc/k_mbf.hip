@@ -621,6 +621,17 @@ __global__ __launch_bounds__(TS == 16 ? 1024 : 512) void mbf_kernel(MbfArgs a) {
   if (a.hpart) {
     constexpr int NWC = HALF / 64;                                        // waves that produced outputs
     float* ssum = reinterpret_cast<float*>(smem + a.off_e);               // [NWC][CC]: the expanded tile is dead
+    // The reduce-FC weights of this thread's hidden unit (8 lanes share unit j = thread / 8; sq <= 64: one unit per thread
+    // group) are requested HERE: their address depends on nothing computed below, the depthwise registers are dead, and the
+    // L2 round trip (~1 us behind the output stores) then runs under the butterfly, the barrier and the channel sums instead of
+    // after them.  (Requested at kernel start they cost eight live registers through every phase and lost, round 4.)
+    const int part = threadIdx.x & 7, ch = part * 8;                      // 8 lanes share one hidden unit j
+    const int jp = threadIdx.x >> 3;
+    f32x4 wp0, wp1;
+    {
+      const f32x4* wp = reinterpret_cast<const f32x4*>(a.se_wr + (int64_t)min(jp, a.sq - 1) * a.Cexp + c0 + min(ch, max(cc - 8, 0)));
+      wp0 = wp[0]; wp1 = wp[1];
+    }
     if (wave < NWC) {
       for (int off = cgp; off < 64; off <<= 1) {
 #pragma unroll
@@ -632,7 +643,6 @@ __global__ __launch_bounds__(TS == 16 ? 1024 : 512) void mbf_kernel(MbfArgs a) {
       }
     }
     __syncthreads();
-    const int part = threadIdx.x & 7, ch = part * 8;                      // 8 lanes share one hidden unit j
     float cs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (ch < cc) {
 #pragma unroll
@@ -650,8 +660,11 @@ __global__ __launch_bounds__(TS == 16 ? 1024 : 512) void mbf_kernel(MbfArgs a) {
     for (int j = threadIdx.x >> 3; j < ((a.sq + 63) & ~63); j += MBF_THREADS / 8) {
       float dot = 0.f;
       if (j < a.sq && ch < cc) {
-        const f32x4* wp = reinterpret_cast<const f32x4*>(a.se_wr + (int64_t)j * a.Cexp + c0 + ch);
-        const f32x4 w0 = wp[0], w1 = wp[1];
+        f32x4 w0 = wp0, w1 = wp1;
+        if (j != jp) {                                                    // (more than MBF_THREADS / 8 hidden units: never at the reference's widths)
+          const f32x4* wp = reinterpret_cast<const f32x4*>(a.se_wr + (int64_t)j * a.Cexp + c0 + ch);
+          w0 = wp[0]; w1 = wp[1];
+        }
         dot = ((w0[0] * cs[0] + w0[1] * cs[1]) + (w0[2] * cs[2] + w0[3] * cs[3])) + ((w1[0] * cs[4] + w1[1] * cs[5]) + (w1[2] * cs[6] + w1[3] * cs[7]));
       }
       dot += __shfl_xor(dot, 1, 64); dot += __shfl_xor(dot, 2, 64); dot += __shfl_xor(dot, 4, 64);
