@@ -563,7 +563,7 @@ int hep_filter(hep_handle* h, const float* boxes, const float* classification, c
   float* d = s.d_det;
   // staged inputs: boxes -> stage 0 (same width as regression), scores 1, rotation 2, translation 3, hand 4
   HIPRET(hipMemcpyAsync(s.d_stage[0], boxes, n * 16, hipMemcpyHostToDevice, s.stream));
-  HIPRET(hipMemcpyAsync(s.d_stage[1], classification, n * 4, hipMemcpyHostToDevice, s.stream));
+  HIPRET(hipMemcpyAsync(s.d_stage[1], classification, n * s.num_classes * 4, hipMemcpyHostToDevice, s.stream));
   HIPRET(hipMemcpyAsync(s.d_stage[2], rotation, n * 12, hipMemcpyHostToDevice, s.stream));
   HIPRET(hipMemcpyAsync(s.d_stage[3], translation, n * 12, hipMemcpyHostToDevice, s.stream));
   HIPRET(hipMemcpyAsync(s.d_stage[4], hand, n * 63 * 4, hipMemcpyHostToDevice, s.stream));

@@ -107,6 +107,9 @@ struct MbfArgs {
   uint32_t vk_rcp, kpv_rcp;                     // filled by launch_mbf: rcp_u32 of K / 8 and kp / 8
   size_t off_e, off_we, off_w, lds_bytes;
   int fp8; const float* we_scale; float a_scale;   // fp8 sessions: e4m3 expand weights (rows padded to 16 bytes), per-channel / per-tensor scales
+  // the squeeze-excite finished in the TAIL of this launch (se_finish.h; alternative plan HEP_SE_TAIL=1, not selected: a launch of its own measured faster): every workgroup writes its
+  // partial row through (sc0 sc1), takes a ticket of its image's counter, and the last one to arrive finishes hidden vector and scale
+  int se_tail; unsigned* tail_counter /* [B] counters, 32 words (one 128-byte line) apart, zero between launches */; SeFinishArgs tail;
   int out_frag;        // store the output in the project GEMM's fragment order [m-tile = 16 rows of (image, pixel)][k-step][lane][8] (k_pw_impl.h FRAG)
   int trace;           // profiling builds (-DHEP_MBF_TRACE): this launch writes its phase time stamps
   int chunks, tiles_x;                          // filled by launch_mbf: channel chunks per tile, tiles per row

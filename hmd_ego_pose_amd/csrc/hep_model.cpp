@@ -232,11 +232,12 @@ enum { F_STEM_W, F_STEM_B, F_STEM_OUT, F_PW_A, F_PW_W, F_PW_B, F_PW_RES, F_PW_OU
        F_SEG_SRC, F_SEG_WDW, F_SEG_WPW, F_SEG_BIAS, F_SEG_OUT, F_CH_EXT_SRC, F_CH_EXT_STORE, F_CH_NODE_OUT, F_CH_WBLOB,
        F_SBF_WS, F_SBF_BS, F_SBF_WDW, F_SBF_BDW, F_SBF_STEM, F_SBF_OUT, F_SBF_PART, F_SBF_WR,
        F_XBF_IN, F_XBF_HPART, F_XBF_SEBR, F_XBF_SEWE, F_XBF_SEBE, F_XBF_BLOB, F_XBF_RES, F_XBF_MID, F_XBF_OUT, F_XBF_PART, F_XBF_WR,
-       F_LATE_IN, F_LATE_BLOB, F_LATE_DS, F_LATE_RES, F_LATE_OUT, F_LATE_HPART, F_HEADS_FEAT, F_HEADS_BLOB, F_HEADS_OUT };
+       F_MBFT_SCALE, F_MBFT_BR, F_MBFT_WE, F_MBFT_BE, F_LATE_IN, F_LATE_BLOB, F_LATE_DS, F_LATE_RES, F_LATE_OUT, F_LATE_HPART, F_HEADS_FEAT, F_HEADS_BLOB, F_HEADS_OUT };
 
 struct Planner {
   Session* s; const Pack& pk; std::string* err; WBuilder wb; bool ok = true;
   std::vector<Ref> refs;
+  int ntails = 0;                     // fused fronts that finish their squeeze-excite in their tail (one counter block each)
   Planner(Session* s_, const Pack& p, std::string* e) : s(s_), pk(p), err(e) { wb.dtype = s_->dtype; }
 
   int tensor(const std::string& name, int H, int W, int C, bool f32 = false) {
@@ -332,7 +333,25 @@ struct Planner {
       const int rows_wg = pmode == 0 ? 64 * pMT : 16 * pMT, per_n = pmode == 1 ? 4 * pNT : pNT;
       const double wgs = (double)((Mmax + rows_wg - 1) / rows_wg) * ((tilesN + per_n - 1) / per_n);
       const double maxmb = getenv("HEP_SE_MAXMB") ? atof(getenv("HEP_SE_MAXMB")) : 4.0;      // (plain getenv: the plan is built once per session)
-      if (wgs * K * se->sqp * es() > maxmb * 1e6) {
+      // ... or no launch at all (HEP_SE_TAIL=1, NOT the default): the fused front that produced the partial rows finishes it in its tail
+      // (k_mbf.hip: last workgroup of an image to arrive).  Measured, round 5, phi 0 b16: 59 -> 49 launches, bit-identical, four in flight
+      // 51.4k against 51.3k frames/s, one batch 0.600 -> 0.605 ms, fp32 one batch 0.980 -> 1.021 ms, phi 3 one batch +2.3 %: the tail
+      // (stores acknowledged, ticket, rows and weight rows fetched past L2 by ONE workgroup) costs 6-9 us against the ~5 us of a launch
+      // and its boundary - the price list's "5-13 us per seam inside a launch" again.
+      int tail_op = -1;
+      if (getenv("HEP_SE_TAIL") && atoi(getenv("HEP_SE_TAIL")) != 0)
+        for (const Ref& r : refs) if (r.field == F_MBF_PART && r.tensor == se->hpart_t) tail_op = r.op;
+      if (wgs * K * se->sqp * es() > maxmb * 1e6 && tail_op >= 0 && ntails < 64) {
+        scale_t = tensor(name + ".se_scale", 1, 1, K, true);
+        MbfArgs& m = s->ops[tail_op].mbf;
+        m.se_tail = 1 + ntails++;          // (1 + index of its counter block; the pointers are patched per lane)
+        m.tail.C = K; m.tail.sq = se->sq; m.tail.sqp = se->sqp; m.tail.rows = se->rows; m.tail.bf16 = s->dtype; m.tail.inv_hw = se->inv_hw;
+        tref(tail_op, F_MBFT_SCALE, scale_t, true);
+        wref(tail_op, F_MBFT_BR, se->br); wref(tail_op, F_MBFT_WE, se->we); wref(tail_op, F_MBFT_BE, se->be);
+        s->ops[tail_op].name += "+se";      // (the launch list shows which fronts carry the finish)
+        s->ops[tail_op].weight_bytes += (double)K * se->sq * es() + ((double)K + se->sq) * 4;
+        s->ops[tail_op].flops_per_image += 2.0 * K * se->sq;
+      } else if (wgs * K * se->sqp * es() > maxmb * 1e6) {
         scale_t = tensor(name + ".se_scale", 1, 1, K, true);
         const int sop = new_op(OP_SE, name.substr(0, name.find('.')) + ".se");
         Op& so = s->ops[sop];
@@ -1591,8 +1610,10 @@ int build_session(Session* s, const Pack& pack, std::string* err) {
     HIPCHK(hipMalloc((void**)&s->d_tanchors, t.size() * 4)); HIPCHK(hipMemcpy(s->d_tanchors, t.data(), t.size() * 4, hipMemcpyHostToDevice));
   }
   HIPCHK(hipEventCreateWithFlags(&s->fork_event, hipEventDisableTiming));
-  HIPCHK(hipMalloc((void**)&s->d_sync, (size_t)s->lanes * s->lane_batch * 64 + 64));
-  HIPCHK(hipMemset(s->d_sync, 0, (size_t)s->lanes * s->lane_batch * 64 + 64));
+  // per lane: 16 words per image for the grouped late kernel, then P.ntails blocks of one 128-byte line per image (arrival tickets of the fronts' tails)
+  const size_t sync_lane_words = (size_t)s->lane_batch * 16 + (size_t)P.ntails * s->lane_batch * 32;
+  HIPCHK(hipMalloc((void**)&s->d_sync, s->lanes * sync_lane_words * 4 + 64));
+  HIPCHK(hipMemset(s->d_sync, 0, s->lanes * sync_lane_words * 4 + 64));
   // ---- one patched copy of the plan per lane: own arena slice, own slice of the head outputs ----
   s->lane_ops.assign(s->lanes, s->ops);
   for (int lane = 0; lane < s->lanes; lane++) {
@@ -1630,7 +1651,11 @@ int build_session(Session* s, const Pack& pack, std::string* err) {
         case F_MBF_WDW: o.mbf.wdw = (const float*)ptr; break;
         case F_MBF_BDW: o.mbf.bdw = (const float*)ptr; break;
         case F_MBF_OUT: o.mbf.out = ptr; break;
-        case F_MBF_PART: o.mbf.hpart = (float*)ptr; break;
+        case F_MBF_PART: o.mbf.hpart = (float*)ptr; o.mbf.tail.hpart = (const float*)ptr; break;
+        case F_MBFT_SCALE: o.mbf.tail.scale = (float*)ptr; break;
+        case F_MBFT_BR: o.mbf.tail.br = (const float*)ptr; break;
+        case F_MBFT_WE: o.mbf.tail.we = ptr; break;
+        case F_MBFT_BE: o.mbf.tail.be = (const float*)ptr; break;
         case F_MBF_WR: o.mbf.se_wr = (const float*)ptr; break;
         case F_MBF_WESCALE: o.mbf.we_scale = (const float*)ptr; break;
         case F_PW_WSCALE: o.pw.wscale = (const float*)ptr; break;
@@ -1685,7 +1710,10 @@ int build_session(Session* s, const Pack& pack, std::string* err) {
         case F_LATE_OUT: o.late.blk[r.seg].out = ptr; break;
       }
     }
-    for (Op& o : ops) if (o.kind == OP_LATE) o.late.counters = s->d_sync + (size_t)lane * s->lane_batch * 16;
+    for (Op& o : ops) {
+      if (o.kind == OP_LATE) o.late.counters = s->d_sync + (size_t)lane * sync_lane_words;
+      if (o.kind == OP_MBF && o.mbf.se_tail) o.mbf.tail_counter = s->d_sync + (size_t)lane * sync_lane_words + (size_t)s->lane_batch * 16 + (size_t)(o.mbf.se_tail - 1) * s->lane_batch * 32;
+    }
     // segment tables to device
     for (Op& o : ops)
       if (o.kind == OP_SEP) {

@@ -6,6 +6,7 @@
 
 #include "hep_dev.h"
 #include "hep_internal.h"
+#include "se_finish.h"
 
 // ------------------------------------------------------------------------------------------------
 // stem: conv3x3 stride 2, TF-SAME pad (0,1) on even sizes, 3 -> Cout, folded BN + swish.
@@ -375,6 +376,13 @@ __global__ __launch_bounds__(256) void dw_kernel(DwArgs a) {
     // thread t owns channel group (first_item + t) % CG.  Two steps, both in a fixed order: G = 256 / C
     // helper groups each add every G-th contribution of a channel, then the G helpers are added up.
     float* chs = dw_smem + (KS * KS + 1) * a.C + 256 * 9;          // [C] channel sums of this block
+    // (this thread's reduce-FC weights - 32 lanes per hidden unit j = thread / 32 - are requested before the four barriers of
+    //  the channel-sum reduction: their L2 round trip runs under it instead of behind it)
+    const int lp = threadIdx.x & 31, jp = threadIdx.x >> 5;
+    constexpr int NPF = 3;
+    float wpf[NPF];
+#pragma unroll
+    for (int i = 0; i < NPF; i++) wpf[i] = a.se_wr[(int64_t)min(jp, a.sq - 1) * (CG * 8) + min(lp + 32 * i, CG * 8 - 1)];
 #pragma unroll
     for (int c = 0; c < 8; c++) red[threadIdx.x][c] = sum[c];
     __syncthreads();
@@ -404,12 +412,18 @@ __global__ __launch_bounds__(256) void dw_kernel(DwArgs a) {
     // the mean and the reduce FC are linear in these sums: hpart[b][block][j] = sum_c wr[j][c] * chs[c]; the
     // project GEMM adds the blocks up and finishes the squeeze-excite in its prologue (k_pw.hip).  32 lanes
     // per hidden unit, lane butterfly in a fixed order.
-    const int lp = threadIdx.x & 31;
     float* hrow = a.hpart + ((int64_t)b * a.blocks_per_image + blk) * a.sqp;
-    for (int j = threadIdx.x >> 5; j < ((a.sq + 7) & ~7); j += 8) {
+    for (int j = jp; j < ((a.sq + 7) & ~7); j += 8) {
       float dot = 0.f;
-      if (j < a.sq)
-        for (int c = lp; c < C; c += 32) dot = fmaf(a.se_wr[(int64_t)j * C + c], chs[c], dot);
+      if (j < a.sq) {
+        if (j == jp) {                     // (same products in the same order as the loop below)
+#pragma unroll
+          for (int i = 0; i < NPF; i++) if (lp + 32 * i < C) dot = fmaf(wpf[i], chs[lp + 32 * i], dot);
+          for (int c = lp + 32 * NPF; c < C; c += 32) dot = fmaf(a.se_wr[(int64_t)j * C + c], chs[c], dot);
+        } else {
+          for (int c = lp; c < C; c += 32) dot = fmaf(a.se_wr[(int64_t)j * C + c], chs[c], dot);
+        }
+      }
 #pragma unroll
       for (int off = 1; off < 32; off <<= 1) dot += __shfl_xor(dot, off, 64);
       if (lp == 0 && j < a.sq) hrow[j] = dot;
@@ -458,72 +472,9 @@ void launch_dw(const DwArgs& a_, hipStream_t s) {
 template <bool BF16>
 __global__ __launch_bounds__(256) void se_finish_kernel(SeFinishArgs a) {
   extern __shared__ float se_sm[];          // hidden [sqp] | helper-group row sums [G][sqp]
-  typedef typename Vec8<BF16>::elem T;
-  typedef typename std::conditional<BF16, u32x4, f32x4>::type raw_t;
-  constexpr int JV = BF16 ? 8 : 4, NV = BF16 ? 6 : 12;     // hidden units per 16-byte vector; vectors held per lane (sqp <= 48)
-  float* hid_s = se_sm;
-  float* red_s = se_sm + a.sqp;
-  const int b = blockIdx.x, sqp = a.sqp, sq = a.sq;
-  const int G = max(1, 256 / sqp);
-  const int grp = threadIdx.x / sqp, j = threadIdx.x - grp * sqp;
   const int per = ((a.C + SE_SPLIT - 1) / SE_SPLIT + 7) & ~7;
   const int c0 = blockIdx.y * per, c1 = min(a.C, c0 + per);
-  // Everything that does not depend on the hidden vector is requested FIRST: this lane's expand-FC weight row, its bias
-  // and the reduce bias.  (No measurable effect on the launch: 4.6 us before and after - the smallest kernels of this
-  // library all measure 3.3-5 us, which is the floor a launch costs on this GPU; kept because it is the shorter chain.)
-  const int V = sqp / JV;
-  const int k0 = c0 + threadIdx.x;
-  const raw_t* wrow = reinterpret_cast<const raw_t*>(reinterpret_cast<const T*>(a.we) + (int64_t)min(k0, a.C - 1) * sqp);
-  raw_t wv[NV];
-#pragma unroll
-  for (int q = 0; q < NV; q++) wv[q] = wrow[min(q, V - 1)];
-  const float bev = a.be[min(k0, a.C - 1)], brv = a.br[min((int)threadIdx.x, sq - 1)];
-  if (grp < G && j < sq) {
-    const float* hp = a.hpart + (int64_t)b * a.rows * sqp + j;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int row = grp;
-    for (; row + 3 * G < a.rows; row += 4 * G) {
-      s0 += hp[(int64_t)row * sqp]; s1 += hp[(int64_t)(row + G) * sqp]; s2 += hp[(int64_t)(row + 2 * G) * sqp]; s3 += hp[(int64_t)(row + 3 * G) * sqp];
-    }
-    for (; row < a.rows; row += G) s0 += hp[(int64_t)row * sqp];
-    red_s[grp * sqp + j] = (s0 + s1) + (s2 + s3);
-  }
-  __syncthreads();
-  if (threadIdx.x < sqp) {
-    float h = 0.f;
-    if (threadIdx.x < sq) {
-      float sacc = 0.f;
-      for (int q = 0; q < G; q++) sacc += red_s[q * sqp + threadIdx.x];
-      h = swishf(fmaf(sacc, a.inv_hw, brv));
-    }
-    hid_s[threadIdx.x] = h;
-  }
-  __syncthreads();
-  // (the same pairing of partial sums as the prologue of the project GEMM: even / odd hidden units)
-  auto fma_vec = [&](const raw_t& w, int v, float& e0, float& e1) {
-    const f32x4 h0 = *reinterpret_cast<const f32x4*>(hid_s + v);
-    if constexpr (BF16) {
-      const f32x4 h1 = *reinterpret_cast<const f32x4*>(hid_s + v + 4);
-      e0 = fmaf(__uint_as_float(w[0] << 16), h0[0], e0); e1 = fmaf(__uint_as_float(w[0] & 0xffff0000u), h0[1], e1);
-      e0 = fmaf(__uint_as_float(w[1] << 16), h0[2], e0); e1 = fmaf(__uint_as_float(w[1] & 0xffff0000u), h0[3], e1);
-      e0 = fmaf(__uint_as_float(w[2] << 16), h1[0], e0); e1 = fmaf(__uint_as_float(w[2] & 0xffff0000u), h1[1], e1);
-      e0 = fmaf(__uint_as_float(w[3] << 16), h1[2], e0); e1 = fmaf(__uint_as_float(w[3] & 0xffff0000u), h1[3], e1);
-    } else {
-      e0 = fmaf(w[0], h0[0], e0); e1 = fmaf(w[1], h0[1], e1); e0 = fmaf(w[2], h0[2], e0); e1 = fmaf(w[3], h0[3], e1);
-    }
-  };
-  for (int k = k0; k < c1; k += 256) {
-    float e0 = 0.f, e1 = 0.f;
-    const raw_t* wr = reinterpret_cast<const raw_t*>(reinterpret_cast<const T*>(a.we) + (int64_t)k * sqp);
-    if (k == k0) {
-#pragma unroll
-      for (int q = 0; q < NV; q++) if (q < V) fma_vec(wv[q], q * JV, e0, e1);
-      for (int q = NV; q < V; q++) fma_vec(wr[q], q * JV, e0, e1);
-    } else {
-      for (int q = 0; q < V; q++) fma_vec(wr[q], q * JV, e0, e1);
-    }
-    a.scale[(int64_t)b * a.C + k] = sigmoidf((e0 + e1) + (k == k0 ? bev : a.be[k]));
-  }
+  se_finish_body<BF16, 256, false>(a, blockIdx.x, c0, c1, threadIdx.x, se_sm);      // (se_finish.h)
 }
 void launch_se_finish(const SeFinishArgs& a, hipStream_t s) {
   const size_t lds = ((size_t)a.sqp + 256 + a.sqp) * sizeof(float);

@@ -412,6 +412,13 @@ __global__ __launch_bounds__(XT, KS == 3 ? 4 : 2) void xbf_kernel(XbfArgs a) {  
 
   // ---------------- P4: channel sums in a fixed order -> partial reduce-FC products of block i ----------------
   float (*red9)[9] = reinterpret_cast<float (*)[9]>(smem);            // [XT][9] (the tile region is dead)
+  // the reduce-FC weights of this thread's hidden unit (32 lanes share unit j = thread / 32) are requested before the two
+  // barriers of the channel-sum reduction: their L2 round trip runs under it instead of behind it (k_mbf.hip phase D, same move)
+  constexpr int NPF = NT2C ? (NT2C * 16 + 31) / 32 : 6;
+  const int lp = tid & 31, jp = tid >> 5;
+  float wpf[NPF];
+#pragma unroll
+  for (int i = 0; i < NPF; i++) wpf[i] = a.se_wr[(uint32_t)(min(jp, a.sq2 - 1) * Cexp + min(lp + 32 * i, Cexp - 1))];
 #pragma unroll
   for (int ci = 0; ci < XCH; ci++) {
     if (ci >= a.nchunks) continue;
@@ -434,12 +441,18 @@ __global__ __launch_bounds__(XT, KS == 3 ? 4 : 2) void xbf_kernel(XbfArgs a) {  
     __syncthreads();
   }
   {
-    const int lp = tid & 31;
     float* hrow = a.hpart_out + ((int64_t)b * wgs + wgt) * a.sqp2;
-    for (int j = tid >> 5; j < ((a.sq2 + 15) & ~15); j += XT / 32) {
+    for (int j = jp; j < ((a.sq2 + 15) & ~15); j += XT / 32) {
       float dot = 0.f;
-      if (j < a.sq2)
-        for (int c = lp; c < Cexp; c += 32) dot = fmaf(a.se_wr[(uint32_t)(j * Cexp + c)], csum_s[c], dot);
+      if (j < a.sq2) {
+        if (j == jp) {                     // (same products in the same order as the loop below)
+#pragma unroll
+          for (int i = 0; i < NPF; i++) if (lp + 32 * i < Cexp) dot = fmaf(wpf[i], csum_s[lp + 32 * i], dot);
+          for (int c = lp + 32 * NPF; c < Cexp; c += 32) dot = fmaf(a.se_wr[(uint32_t)(j * Cexp + c)], csum_s[c], dot);
+        } else {
+          for (int c = lp; c < Cexp; c += 32) dot = fmaf(a.se_wr[(uint32_t)(j * Cexp + c)], csum_s[c], dot);
+        }
+      }
 #pragma unroll
       for (int off = 1; off < 32; off <<= 1) dot += __shfl_xor(dot, off, 64);
       if (lp == 0 && j < a.sq2) hrow[j] = dot;

@@ -450,6 +450,24 @@ def test_classifier_with_several_classes(api, tag, monkeypatch):
             for key, want in zip(("boxes", "scores", "labels", "rotation", "translation", "hand", "index"), o):
                 assert np.array_equal(det[key][i].cpu().numpy(), want), (thr, M, i, key)
             assert int(det["count"][i]) == int((o[6] >= 0).sum())
+    # the host-buffer entry points (what the C# twins bind): hep_run fills [batch, N, classes], hep_filter stages that many scores
+    capi = api["capi"]; lib = capi.lib(); N = s.num_anchors
+    ho = [np.empty((batch, N, k), np.float32) for k in s.out_width]
+    xc = np.ascontiguousarray(x.numpy())
+    capi.check(lib.hep_run(s.handle, xc.ctypes.data, batch, None, *[o.ctypes.data for o in ho]))
+    assert np.array_equal(ho[1], cls.cpu().numpy()) and np.array_equal(ho[4], hand.cpu().numpy())
+    M = 20
+    hb, ht = boxes.cpu().numpy(), trans.cpu().numpy()
+    hd = [np.empty((batch, M, 4), np.float32), np.empty((batch, M), np.float32), np.empty((batch, M), np.int32), np.empty((batch, M, 3), np.float32),
+          np.empty((batch, M, 3), np.float32), np.empty((batch, M, 63), np.float32), np.empty((batch, M), np.int32), np.empty((batch,), np.int32)]
+    capi.check(lib.hep_filter(s.handle, hb.ctypes.data, ho[1].ctypes.data, ho[2].ctypes.data, ht.ctypes.data, ho[4].ctypes.data, batch,
+                              0.5, 0.5, M, *[a.ctypes.data for a in hd]))
+    for i in range(batch):
+        o = D.filter_detections(hb[i], ho[1][i], ho[2][i], ht[i], ho[4][i], score_threshold=0.5, max_detections=M, nms_threshold=0.5)
+        assert np.array_equal(hd[6][i], o[6]) and np.array_equal(hd[2][i], o[2]) and np.array_equal(hd[1][i], o[1]), i
+    dims = (ctypes.c_int64 * 4)(); nd = ctypes.c_int()
+    capi.check(lib.hep_output_shape(s.handle, 6, batch, dims, ctypes.byref(nd)))
+    assert list(dims)[:3] == [batch, N, classes] and nd.value == 3 and lib.hep_num_classes(s.handle) == classes
     # bf16 session of the same weights: same shapes, finite, the classes in the same order
     sb = api["Session"](sd, phi, size, batch, "bf16")
     cb = sb.forward(x.cuda())[2].float().cpu()
@@ -545,7 +563,9 @@ ALT_PLANS = [
     ({"HEP_CHAIN": "1"}, lambda ks: any("sep_kernel<false, 2" in y for _, y in ks) and not any("chain_kernel" in y for _, y in ks)),
     ({"HEP_CHAIN_F32": "0"}, lambda ks: any("sep_kernel<false, 2" in y for _, y in ks) and not any("chain_kernel" in y for _, y in ks)),
     ({"HEP_SE_MAXMB": "0"}, lambda ks: sum("se_finish_kernel" in y for _, y in ks) >= 12),
-    ({"HEP_SE_MAXMB": "1000"}, lambda ks: not any("se_finish_kernel" in y for _, y in ks)),
+    ({"HEP_SE_TAIL": "1"}, lambda ks: sum(n.endswith(".front+se") for n, _ in ks) >= 1 and not any("se_finish_kernel" in y for _, y in ks)),       # the finish in the tail of the fused fronts (last workgroup of an image to arrive)
+    ({"HEP_SE_TAIL": "1", "HEP_SE_MAXMB": "0"}, lambda ks: sum(n.endswith(".front+se") for n, _ in ks) >= 11 and sum("se_finish_kernel" in y for _, y in ks) <= 1),
+    ({"HEP_SE_MAXMB": "1000"}, lambda ks: not any("se_finish_kernel" in y for _, y in ks) and not any(n.endswith("+se") for n, _ in ks)),
     ({"HEP_PWG": "0", "HEP_PW_MT2": "0"}, lambda ks: not any("pw_group_kernel" in y for _, y in ks)),
     ({"HEP_TOWER": "0"}, lambda ks: not any("tower_" in y for _, y in ks)),
     ({"HEP_TOWER_COOP": "0"}, lambda ks: any(y.startswith("tower_kernel<") for _, y in ks) and not any("tower_coop_kernel" in y for _, y in ks)),   # wave-per-patch heads
@@ -600,8 +620,9 @@ def test_default_fp32_plan_uses_multi_pass_fronts(api):
     s = api["Session"](api["sd"](0, 4), 0, 256, 16, "fp32")
     plan = dict(_plan_syms(s, 16))
     s.close()
-    assert plan["b9.front"] == "mbf_kernel<false, 5, 1, 16, false, 1>" and plan["b10.front"] == plan["b9.front"], plan
-    assert all(plan[f"b{i}.front"].endswith(", 8, false, 1>") for i in (12, 13, 14, 15)), plan
+    front = lambda i: plan.get(f"b{i}.front+se", plan.get(f"b{i}.front"))       # ("+se": the front finishes the squeeze-excite in its tail)
+    assert front(9) == "mbf_kernel<false, 5, 1, 16, false, 1>" and front(10) == front(9), plan
+    assert all(front(i).endswith(", 8, false, 1>") for i in (12, 13, 14, 15)), plan
 
 
 def test_default_fp32_plan_runs_its_chains_in_lds(api):
@@ -764,11 +785,12 @@ def test_late_block_kernel_alternative_plan(api, batch, group, monkeypatch):
     s0.forward(x.cuda())
     want12 = s0.stage("block12", batch).float().cpu()
     n0 = len(s0.kernels(batch))
+    replaced = sum(n.split(".")[0] in ("b12", "b13", "b14", "b15") for n, *_ in s0.kernels(batch))      # fronts (+ their squeeze-excite launches) + projects
     s0.close()
     monkeypatch.setenv("HEP_LATE", "1")
     s = api["Session"](sd, phi, size, batch, "bf16", flags=api["capi"].FLAG_KEEP_INTERMEDIATES)
     plan = _plan_syms(s, batch)
-    assert [n for n, y in plan if y == "late_kernel"] == ["b12-b15.blocks"] and len(plan) == n0 - 11, plan
+    assert [n for n, y in plan if y == "late_kernel"] == ["b12-b15.blocks"] and len(plan) == n0 - replaced + 1 and replaced in (8, 12), plan
     first = [t.clone() for t in s.forward(x.cuda())[1:]]
     got12 = s.stage("block12", batch).float().cpu()
     for _ in range(3):
