@@ -182,4 +182,23 @@ __device__ __forceinline__ void hep_poison_lds(void* smem, size_t bytes) {
 #define HEP_POISON(smem, bytes) hep_poison_lds(smem, bytes)
 #else
 #define HEP_POISON(smem, bytes)
+
+// One dword of every 64-byte line of a by-value kernel argument struct (<= 512 bytes) is requested at once and waited for: the
+// compiler fetches argument fields next to their first use, in several dependent groups, and each group that starts a new line is a
+// scalar-cache miss (~0.2 us) in the prologue of a latency-bound workgroup.  Behind this the later loads hit the scalar cache.
+// (Inline asm: a plain C++ read of the same memory is folded into the field's own late load.)
+template <int BYTES> __device__ __forceinline__ void kernarg_warm() {
+  static_assert(BYTES >= 4 && BYTES <= 512, "eight lines");
+  constexpr int L = BYTES - 4;
+  typedef const __attribute__((address_space(4))) uint32_t* cptr;
+  cptr kp = (cptr)__builtin_amdgcn_kernarg_segment_ptr();
+  uint32_t t0, t1, t2, t3, t4, t5, t6, t7;
+  asm volatile("s_load_dword %0, %8, %9\n\ts_load_dword %1, %8, %10\n\ts_load_dword %2, %8, %11\n\ts_load_dword %3, %8, %12\n\t"
+               "s_load_dword %4, %8, %13\n\ts_load_dword %5, %8, %14\n\ts_load_dword %6, %8, %15\n\ts_load_dword %7, %8, %16\n\t"
+               "s_waitcnt lgkmcnt(0)"
+               : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3), "=&s"(t4), "=&s"(t5), "=&s"(t6), "=&s"(t7)
+               : "s"(kp), "i"(0), "i"(64 < L ? 64 : L), "i"(128 < L ? 128 : L), "i"(192 < L ? 192 : L), "i"(256 < L ? 256 : L), "i"(320 < L ? 320 : L), "i"(384 < L ? 384 : L), "i"(448 < L ? 448 : L)
+               : "memory");
+}
+
 #endif
