@@ -183,6 +183,8 @@ __device__ __forceinline__ void hep_poison_lds(void* smem, size_t bytes) {
 #else
 #define HEP_POISON(smem, bytes)
 
+#endif
+
 // One dword of every 64-byte line of a by-value kernel argument struct (<= 512 bytes) is requested at once and waited for: the
 // compiler fetches argument fields next to their first use, in several dependent groups, and each group that starts a new line is a
 // scalar-cache miss (~0.2 us) in the prologue of a latency-bound workgroup.  Behind this the later loads hit the scalar cache.
@@ -200,5 +202,3 @@ template <int BYTES> __device__ __forceinline__ void kernarg_warm() {
                : "s"(kp), "i"(0), "i"(64 < L ? 64 : L), "i"(128 < L ? 128 : L), "i"(192 < L ? 192 : L), "i"(256 < L ? 256 : L), "i"(320 < L ? 320 : L), "i"(384 < L ? 384 : L), "i"(448 < L ? 448 : L)
                : "memory");
 }
-
-#endif
