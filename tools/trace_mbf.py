@@ -1,7 +1,7 @@
 import sys, ctypes; import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from hmd_ego_pose_amd import _capi
-_capi.LIB_PATH = os.path.join(os.path.dirname(_capi.LIB_PATH), "libhep_trace.so")     # make -C hmd_ego_pose_amd/csrc trace
+_capi.LIB_PATH = os.environ.get("HEP_TRACE_LIB") or os.path.join(os.path.dirname(_capi.LIB_PATH), "libhep_trace.so")     # make -C hmd_ego_pose_amd/csrc trace
 from hmd_ego_pose_amd.model import Session
 from hmd_ego_pose_amd.weights import seeded_state_dict
 B=int(sys.argv[1]); nblocks=int(sys.argv[2])
