@@ -26,6 +26,13 @@ only at the timing barriers.  Rank 0 prints ONE JSON line.  It also carries
                 launch duration measured here with HIP events, against 8 TB/s HBM3E; `layers` lists every launch
   cpu_baseline  (N=1) the CPU oracle (torch fp32 restatement of the reference) timed on the host
                 cores in the evaluate.py regime (batch 1, anchors rebuilt per call, decode).
+  latency_b1    (N=1) the only regime the reference publishes a number for (unity-sandbox/WebRTCNetCoreSandbox/Program.cs:24-33:
+                "effnet_b0_512", FP32, batch 1, prep + inference 175 / 40 / 16 ms on the ONNXRuntime CPU / CUDA / TensorRT providers,
+                + 6-8 ms preprocessing): phi 0 at 512x512, fp32, batch 1, called through the C ABI the way the C# host would -
+                p50 / p99 over >= 200 calls, and the model-load time (hep_create).
+The timed loop is fed by one submission thread per stream (joined before the closing barrier; a thread that raises fails the run):
+after a synchronize the first graph launch costs the host ~140 us, and with one Python thread the other streams wait behind it.
+`single_thread_value` is the same loop submitted from one thread.
 """
 import argparse
 import ctypes
@@ -35,6 +42,7 @@ import socket
 import subprocess
 import sys
 import tempfile
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -137,6 +145,111 @@ def add_vs_ref(phi, size, precisions=("fp32", "bf16", "fp8")):
     return out
 
 
+def latency_b1(dev, calls=300):
+    """The reference's only published performance regime (unity-sandbox/WebRTCNetCoreSandbox/Program.cs:24-33: "effnet_b0_512", FP32,
+    batch 1; preparation of a frame 6-8 ms, prep + inference 175 ms / 40 ms / 16 ms on the ONNXRuntime CPU / CUDA / TensorRT providers
+    of an RTX 3090 + Ryzen 3900X box, model load < 10 s / ~1 min / ~10 min), through the C ABI as the C# host would call it:
+      host  : hep_run (host float[1,3,512,512] in, the five head arrays out - what replaces Session.Run, Program.cs:211-229)
+              -> hep_decode -> hep_filter, everything in host memory, one call after the other, each returning when its result is there;
+      frame : the app's frame callback (Program.cs:140-205) with the frame bytes in host memory: H2D copy of one 1280x720 I420 frame ->
+              hep_preprocess_i420_device (YV12 -> BGR, centre crop 256, resize 512, normalise) -> hep_run_device -> hep_decode_device ->
+              hep_filter_device -> D2H copy of the detection rows -> stream synchronize.
+    Wall-clock per call, p50 / p99 over `calls` calls after 20 warm-up calls; the classifier header's bias is shifted so that ~30 of the
+    49 104 anchors pass the 0.5 threshold (a trained network's rate; the seeded classifier passes ~40 %, which would time a pathological
+    sort + NMS) - the same load knob as the comm loop's, every other tensor and the arithmetic are the parity-tested ones."""
+    import numpy as np
+    import torch
+    from hmd_ego_pose_amd import _capi
+    from hmd_ego_pose_amd.model import Session
+    from hmd_ego_pose_amd.weights import pack_bytes, seeded_state_dict
+    lib = _capi.lib()
+    phi, S, M = 0, 512, 100
+    sd = seeded_state_dict(phi, 0)
+    blob = pack_bytes(sd)
+    t0 = time.perf_counter()
+    h = ctypes.c_void_p()
+    _capi.check(lib.hep_create_from_memory(blob, len(blob), phi, S, 1, _capi.HEP_F32, dev.index or 0, 0, ctypes.byref(h)))
+    load_ms = (time.perf_counter() - t0) * 1e3          # weight pack parse + BatchNorm fold + layout + upload + arena (the graph is captured by the first run)
+    lib.hep_destroy(h)
+    rng = np.random.Generator(np.random.PCG64(5))
+    x = rng.standard_normal((1, 3, S, S)).astype(np.float32)
+    # classifier bias shift: the quantile of the logits that leaves ~30 candidates, found in a few rounds (the top scores of the seeded
+    # network saturate to 1.0 in fp32, so one round cannot see how far above the threshold they sit)
+    shift = 0.0
+    for _ in range(6):
+        sd_l = dict(sd); sd_l[CLS_BIAS_KEY] = sd[CLS_BIAS_KEY] - shift
+        s = Session(sd_l, phi, S, 1, "fp32", dev)
+        p = s.forward(torch.from_numpy(x).to(dev), want_features=False)[2].double().flatten()
+        n_pass = int((p > 0.5).sum())
+        if 10 <= n_pass <= 60:
+            break
+        pc = p.clamp(1e-6, 1 - 1e-6)
+        shift += float(torch.quantile(torch.log(pc / (1 - pc)), 1.0 - 30.0 / p.numel()))
+        s.close()
+    N = s.num_anchors
+    cam = np.array([[480, 480, 128, 128, 1000, 1.0]], np.float32)
+    ho = [np.empty((1, N, k), np.float32) for k in s.out_width]
+    hb, ht = np.empty((1, N, 4), np.float32), np.empty((1, N, 3), np.float32)
+    hd_ = [np.empty((1, M, 4), np.float32), np.empty((1, M), np.float32), np.empty((1, M), np.int32), np.empty((1, M, 3), np.float32),
+           np.empty((1, M, 3), np.float32), np.empty((1, M, 63), np.float32), np.empty((1, M), np.int32), np.empty((1,), np.int32)]
+    t0 = time.perf_counter()
+    _capi.check(lib.hep_run(s.handle, x.ctypes.data, 1, None, *[o.ctypes.data for o in ho]))
+    first_ms = (time.perf_counter() - t0) * 1e3          # first host-ABI call of the handle (staging buffers)
+    thr = 0.5
+
+    def host_call():
+        _capi.check(lib.hep_run(s.handle, x.ctypes.data, 1, None, *[o.ctypes.data for o in ho]))
+        _capi.check(lib.hep_decode(s.handle, ho[0].ctypes.data, ho[3].ctypes.data, cam.ctypes.data, 1, hb.ctypes.data, ht.ctypes.data))
+        _capi.check(lib.hep_filter(s.handle, hb.ctypes.data, ho[1].ctypes.data, ho[2].ctypes.data, ht.ctypes.data, ho[4].ctypes.data, 1, thr, 0.5, M,
+                                   *[a.ctypes.data for a in hd_]))
+
+    FH, FW = 720, 1280
+    frame = torch.from_numpy(rng.integers(0, 256, (1, FH * FW * 3 // 2), dtype=np.uint8))
+    st = torch.cuda.Stream(dev)
+    cam_d = torch.from_numpy(cam).to(dev)
+    pre = torch.empty((1, S, S, 3), dtype=torch.float32, device=dev)
+    xv = pre.permute(0, 3, 1, 2)
+    xstr = (ctypes.c_int64 * 4)(*xv.stride())
+    bx, tr = torch.empty((1, N, 4), device=dev), torch.empty((1, N, 3), device=dev)
+    f = lambda *sh: torch.empty(sh, dtype=torch.float32, device=dev)
+    i = lambda *sh: torch.empty(sh, dtype=torch.int32, device=dev)
+    det = [f(1, M, 4), f(1, M), i(1, M), f(1, M, 3), f(1, M, 3), f(1, M, 63), i(1, M), i(1)]
+    counts = []
+
+    def frame_call():
+        with torch.cuda.stream(st):
+            fd = frame.to(dev, non_blocking=True)
+            _capi.check(lib.hep_preprocess_i420_device(s.handle, fd.data_ptr(), 1, FH, FW, 256, 512, pre.data_ptr(), st.cuda_stream))
+            _capi.check(lib.hep_run_device(s.handle, xv.data_ptr(), xstr, 1, None, None, st.cuda_stream))
+            _capi.check(lib.hep_decode_device(s.handle, None, None, cam_d.data_ptr(), 1, bx.data_ptr(), tr.data_ptr(), st.cuda_stream))
+            _capi.check(lib.hep_filter_device(s.handle, bx.data_ptr(), None, None, tr.data_ptr(), None, 1, thr, 0.5, M, *[d.data_ptr() for d in det], st.cuda_stream))
+            rows = [d.cpu() for d in det]                # D2H of the detection rows (synchronises the stream)
+        counts.append(int(rows[7][0]))
+
+    def pct(fn):
+        for _ in range(20):
+            fn()
+        torch.cuda.synchronize(dev)
+        ts = []
+        for _ in range(calls):
+            t0 = time.perf_counter(); fn(); ts.append((time.perf_counter() - t0) * 1e3)
+        ts.sort()
+        return {"p50_ms": round(ts[len(ts) // 2], 4), "p99_ms": round(ts[min(len(ts) - 1, int(len(ts) * 0.99))], 4), "min_ms": round(ts[0], 4), "mean_ms": round(sum(ts) / len(ts), 4)}
+
+    host = pct(host_call)
+    n_host = int(hd_[7][0])
+    fr = pct(frame_call)
+    s.close()
+    return {"host": host, "frame": fr, "calls": calls, "model_load_ms": round(load_ms, 1), "first_call_ms": round(first_ms, 1),
+            "detections_per_frame": {"host": n_host, "frame": counts[-1] if counts else None}, "score_threshold": thr, "classifier_bias_shift": round(-shift, 3),
+            "config": "EfficientPose phi=0 512x512 fp32 batch=1 (the reference's \"effnet_b0_512\", FP32), seeded random-init weights, N(0,1) input / random I420 frame bytes",
+            "what": "host: hep_run -> hep_decode -> hep_filter on host arrays (in: 3 MB, out: 14.5 MB of raw heads per call over PCIe, as the C# host consumes them); "
+                    "frame: 1280x720 I420 bytes in host memory -> H2D -> hep_preprocess_i420_device -> hep_run_device -> hep_decode_device -> hep_filter_device -> D2H of the <= 100 detection rows",
+            "reference_published": {"prep_ms": "6-8", "prep_plus_inference_ms": {"onnxruntime_cpu": 175, "onnxruntime_cuda": 40, "onnxruntime_tensorrt": 16},
+                                    "model_load": {"cpu": "< 10 s", "cuda": "~1 min", "tensorrt": "~10 min"},
+                                    "hardware": "RTX 3090 + Ryzen 3900X, Windows, with Unity running", "source": "unity-sandbox/WebRTCNetCoreSandbox/Program.cs:24-33"}}
+
+
 def pmc_traffic(symbol, tag=""):
     """HBM bytes per launch of `symbol` from the newest committed PMC pass of this configuration
     (profiles/r*/*_pmc_per_kernel.json for the default workload, *_phi3_pmc_per_kernel.json for phi 3 @ 512 b8, *_fp32_pmc_per_kernel.json for fp32 sessions:
@@ -220,6 +333,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-comm", action="store_true", help="skip the scatter -> preprocess -> forward -> filter -> gather loop")
     ap.add_argument("--no-fp32", action="store_true", help="skip the fp32 (accuracy-bound-meeting) throughput block")
     ap.add_argument("--no-layers", action="store_true", help="omit roofline.layers (one row per launch)")
+    ap.add_argument("--no-latency", action="store_true", help="skip the latency_b1 block (phi 0 @ 512 fp32 batch 1 through the host C ABI)")
+    ap.add_argument("--submit-threads", type=int, default=1, choices=[0, 1], help="1: one submission thread per stream feeds the timed loop (default); 0: the single-thread loop")
     ap.add_argument("--sustain-seconds", type=float, default=2.0, help="length of the `sustained` run (0: skip)")
     ap.add_argument("--comm-score-threshold", type=float, default=0.5)
     ap.add_argument("--comm-depth", type=int, default=4, help="batches in flight in the serving (comm) loop, at most --inflight")
@@ -339,6 +454,50 @@ def main():
     strides = (ctypes.c_int64 * 4)(*xs[0].stride())
     streams = [torch.cuda.Stream(dev) for _ in range(D)]
 
+    class Submitters:
+        """One persistent submission thread per stream: thread d enqueues the steps d, d + D, d + 2 D, ... of a window on stream d
+        (ctypes releases the GIL inside the C call).  submit() returns when every thread has enqueued its share; an exception in
+        a thread is re-raised there, a thread that does not come back within two minutes fails the run instead of hanging it."""
+        def __init__(self, step):
+            self.step = step
+            self.go = [threading.Semaphore(0) for _ in range(D)]
+            self.done = threading.Semaphore(0)
+            self.K, self.err, self.stop = 0, None, False
+            self.th = [threading.Thread(target=self._run, args=(d,), daemon=True) for d in range(D)]
+            for t in self.th:
+                t.start()
+
+        def _run(self, d):
+            torch.cuda.set_device(dev)
+            while True:
+                self.go[d].acquire()
+                if self.stop:
+                    return
+                try:
+                    for i in range(d, self.K, D):
+                        self.step(i)
+                except BaseException as e:      # noqa: BLE001  (handed to the submitting thread)
+                    self.err = e
+                finally:
+                    self.done.release()
+
+        def submit(self, K):
+            self.K = K
+            for g in self.go:
+                g.release()
+            for _ in range(D):
+                if not self.done.acquire(timeout=120):
+                    raise RuntimeError("bench.py: a submission thread did not return within 120 s")
+            if self.err is not None:
+                raise self.err
+
+        def close(self):
+            self.stop = True
+            for g in self.go:
+                g.release()
+            for t in self.th:
+                t.join(5)
+
     class Loop:
         """D sessions of one precision and the step they run."""
         def __init__(self, precision):
@@ -350,6 +509,15 @@ def main():
             for d in range(D):            # set-up, not measurement: every session captures its hipGraph on first use
                 self.step(d)
             torch.cuda.synchronize(dev)
+            self.pool = Submitters(self.step) if (args.submit_threads and D > 1) else None
+
+        def run(self, steps, depth=D, threads=True):
+            """enqueue `steps` steps: from the per-stream submission threads when all D streams are in use, else from this thread"""
+            if self.pool is not None and threads and depth == D:
+                self.pool.submit(steps)
+            else:
+                for i in range(steps):
+                    self.step(i, depth)
 
         def step(self, i, depth=D):
             # forward into the handle's own output buffers (no copies), then decode from them
@@ -358,27 +526,31 @@ def main():
             _capi.check(lib.hep_run_device(self.sess[d].handle, xs[d].data_ptr(), strides, B, None, None, st))
             _capi.check(lib.hep_decode_device(self.sess[d].handle, None, None, cam.data_ptr(), B, self.boxes[d].data_ptr(), self.trans[d].data_ptr(), st))
 
-        def timed(self, steps, depth=D):
+        def timed(self, steps, depth=D, threads=True):
             torch.cuda.synchronize(dev); t0 = time.perf_counter()
-            for i in range(steps):
-                self.step(i, depth)
+            self.run(steps, depth, threads)
             torch.cuda.synchronize(dev)
             return time.perf_counter() - t0
 
         def close(self):
+            if self.pool is not None:
+                self.pool.close(); self.pool = None
             for s_ in self.sess:
                 s_.close()
 
     main_loop = Loop(args.precision)
     N = main_loop.sess[0].num_anchors
-    for i in range(args.warmup):
-        main_loop.step(i)
+    main_loop.run(args.warmup)
     hd.barrier(); torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        main_loop.step(i)
+    main_loop.run(args.steps)           # EXACTLY --steps steps: submission thread d enqueues steps d, d + D, ... on stream d and is joined here
     torch.cuda.synchronize(dev); hd.barrier()
     elapsed = hd.max_over_ranks(time.perf_counter() - t0, dev)
+    # the same window submitted from ONE thread (what `value` was until round 5): a side figure
+    single_elapsed = None
+    if main_loop.pool is not None:
+        main_loop.timed(args.warmup, threads=False)
+        single_elapsed = hd.max_over_ranks(main_loop.timed(args.steps, threads=False), dev)
     assert all(torch.isfinite(t).all() for t in main_loop.boxes) and all(torch.isfinite(t).all() for t in main_loop.trans)
 
     # ---- the same loop for >= sustain_seconds, in 10 sub-windows (a 20-step run is 7 ms: this is the figure to trust) ----
@@ -476,8 +648,11 @@ def main():
                                    f"+ box/translation decode; seeded random-init weights, N(0,1) frames resident in HBM; "
                                    f"{D} batches of {B} in flight per GPU on {D} HIP streams",
                        "phi": phi, "size": S, "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
-                       "batches_in_flight": D, "anchors": N, "launches_per_step": len(main_loop.sess[0].kernels(B)) + 1},
+                       "batches_in_flight": D, "anchors": N, "launches_per_step": len(main_loop.sess[0].kernels(B)) + 1,
+                       "submission_threads": D if main_loop.pool is not None else 1},
         }
+        if single_elapsed is not None:
+            out["single_thread_value"] = round(B * world * args.steps / single_elapsed, 2)
         if sustained is not None:
             out["sustained"] = sustained
         if comm is not None:
@@ -513,6 +688,12 @@ def main():
                                "roofline": launch_profile(f32.sess[0], B, ef / args.steps * 1e3, ef1 / k1 * 1e3,
                                                           (lambda y: pmc_traffic(y, "fp32_")) if (phi, S, B) == (0, 256, 16) else None, layers=not args.no_layers)}
                 f32.close()
+            if not args.no_latency and (phi, S, B) == (0, 256, 16):
+                lat = latency_b1(dev)
+                out["latency_b1"] = lat
+                out["latency_b1_ms_p50"] = lat["frame"]["p50_ms"]; out["latency_b1_ms_p99"] = lat["frame"]["p99_ms"]       # prep + inference from frame bytes (the reference's 6-8 ms + 16 / 40 / 175 ms)
+                out["latency_b1_host_ms_p50"] = lat["host"]["p50_ms"]; out["latency_b1_host_ms_p99"] = lat["host"]["p99_ms"]   # Session.Run replacement on host arrays + decode + filter
+                out["latency_b1_model_load_ms"] = lat["model_load_ms"]
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(phi, S)
                 out["add_vs_ref"] = add_vs_ref(phi, S)

@@ -24,6 +24,7 @@ _P = c_void_p
 _FP = c_void_p          # float* passed as raw addresses
 SYMBOLS = {
     "hep_abi_version": (c_int, []),
+    "hep_build_info": (c_char_p, []),
     "hep_last_error": (c_char_p, []),
     "hep_device_count": (c_int, []),
     "hep_create": (c_int, [c_char_p, c_int, c_int, c_int, c_int, c_int, c_uint, POINTER(_P)]),

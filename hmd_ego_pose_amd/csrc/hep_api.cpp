@@ -72,6 +72,7 @@ void launch_op(const Session& s, const Op& op, int batch, hipStream_t st, const 
     case OP_CHAIN: { ChainArgs a = op.chain; a.B = batch; launch_chain(a, st); break; }
     case OP_SE: { SeFinishArgs a = op.se; a.B = batch; launch_se_finish(a, st); break; }
     case OP_XBF: { XbfArgs a = op.xbf; a.B = batch; launch_xbf(a, st); break; }
+#ifdef HEP_ALT
     case OP_LATE: { LateArgs a = op.late; a.B = batch; launch_late(a, st); break; }
     case OP_HEADS: { HeadsArgs a = op.heads; a.B = batch; launch_heads(a, st); break; }
     case OP_SBF: {
@@ -79,6 +80,7 @@ void launch_op(const Session& s, const Op& op, int batch, hipStream_t st, const 
       a.sn = strides[0]; a.sc = strides[1]; a.sh = strides[2]; a.sw = strides[3];
       launch_sbf(a, st); break;
     }
+#endif
     case OP_SEP: {
       SepArgs a = op.sep; a.B = batch;
       if (a.direct) launch_tower(a, st);
@@ -196,6 +198,22 @@ static int calibrate_fp8(Session& s, const float* frames_dev = nullptr, int nfra
 extern "C" {
 
 int hep_abi_version(void) { return HEP_ABI_VERSION; }
+const char* hep_build_info(void) {
+  return "libhep gfx950"
+#ifdef HEP_ALT
+         " alt"
+#endif
+#ifdef HEP_WITH_FP8
+         " fp8"
+#endif
+#ifdef HEP_POISON_LDS
+         " poison"
+#endif
+#if defined(HEP_MBF_TRACE) || defined(HEP_TOWER_TRACE) || defined(HEP_PW_TRACE) || defined(HEP_XBF_TRACE)
+         " trace"
+#endif
+      ;
+}
 const char* hep_last_error(void) { return g_err.c_str(); }
 
 int hep_device_count(void) try {
@@ -231,8 +249,8 @@ int hep_create_from_memory(const void* pack, size_t pack_bytes, int phi, int siz
     return fail(HEP_ERR_DEVICE, std::string("device is ") + prop.gcnArchName + ", libhep is built for gfx950 (MI355X) only");
   s.size = size; s.max_batch = max_batch; s.dtype = dtype; s.device = device; s.flags = flags;
   {   // lanes: slices of the batch that run as parallel graph branches (HEP_LANES overrides)
-    int lanes = 1;   // measured on MI355X at bs16: 2/4/8 lanes are 4 % / 75 % / 150 % SLOWER (kernels contend instead of overlapping)
-    if (const char* e = getenv("HEP_LANES")) lanes = atoi(e);
+    s.knobs = read_knobs();
+    int lanes = s.knobs.lanes;   // 1: measured on MI355X at bs16, 2/4/8 lanes are 4 % / 75 % / 150 % SLOWER (kernels contend instead of overlapping)
     lanes = std::max(1, std::min(lanes, std::min(max_batch, 16)));
     s.lane_batch = (max_batch + lanes - 1) / lanes;
     s.lanes = (max_batch + s.lane_batch - 1) / s.lane_batch;
@@ -756,9 +774,11 @@ int hep_kernel_symbol(const hep_handle* h, int i, const char** symbol) try {
     case OP_MBF: snprintf(tmp, sizeof tmp, "mbf_kernel<%s, %d, %d, %d, %s, %d>", t, o.mbf.k, o.mbf.s, o.mbf.ts, o.mbf.fp8 ? "true" : "false",
                           o.mbf.has_expand && o.mbf.npass > 1 ? (o.mbf.mp_resident ? 2 : 1) : 0);      // (last argument: 1 / 2 = multi-pass expand)
                  break;
+#ifdef HEP_ALT
     case OP_SBF: snprintf(tmp, sizeof tmp, "sbf_kernel<%s>", t); break;
     case OP_LATE: snprintf(tmp, sizeof tmp, "late_kernel"); break;
     case OP_HEADS: snprintf(tmp, sizeof tmp, "heads_kernel"); break;
+#endif
     case OP_XBF: { const int sp = xbf_specialised(o.xbf);
                    snprintf(tmp, sizeof tmp, "xbf_kernel<%s, %d, %d, %d, %d, %d, %d, %d>", t, o.xbf.k, o.xbf.s, o.xbf.toh, o.xbf.tow, o.xbf.NT1, sp ? o.xbf.K1 : 0, sp ? o.xbf.NT2 : 0); break; }
     default: if (o.sep.direct) snprintf(tmp, sizeof tmp, "%s<%s, %d, %s>", o.sep.coop ? "tower_coop_kernel" : "tower_kernel", t, o.sep.C, o.sep.direct == 2 ? "true" : "false");
@@ -846,13 +866,17 @@ int hep_profile_concurrent(hep_handle* h, int batch, int iters, int nstreams, fl
     // time per launch with the chip shared is what the launch costs a pipeline of batches in flight
     for (int rep = 0; rep < 2; rep++) {
       auto t0 = std::chrono::steady_clock::now();
+      long issued = 0;
       for (int i = 0; i < (rep ? iters : 2); i++)
         for (auto& x : ss) {
           launch_op(s, s.lane_ops[0][k], s.lane_count(batch, 0), x, s.d_in, st);
-          if (s.lane_ops[0][k].kind == OP_LATE && s.lane_ops[0][k].late.G > 1) break;      // (grouped launches of ONE session share its meeting counters: never two at once)
+          issued++;
+#ifdef HEP_ALT
+          if (s.lane_ops[0][k].kind == OP_LATE && s.lane_ops[0][k].late.G > 1) break;      // (grouped launches of ONE session share its meeting counters: never two at once - that row is a SERIAL cost)
+#endif
         }
       for (auto& x : ss) HIPRET(hipStreamSynchronize(x));
-      if (rep) per_kernel_ms[k] = (float)(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / (iters * nstreams));
+      if (rep) per_kernel_ms[k] = (float)(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / (double)std::max(1L, issued));      // per launch ISSUED
     }
   }
   return 0;

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "hep_internal.h"
+#include "hep_knobs.h"
 
 namespace hep {
 
@@ -50,7 +51,10 @@ struct TensorDesc {
 enum OpKind { OP_STEM, OP_PW, OP_DW, OP_POOL, OP_SEP, OP_MBF, OP_PWG, OP_CHAIN, OP_SE, OP_XBF, OP_SBF, OP_LATE, OP_HEADS };
 struct Op {
   OpKind kind; std::string name;
-  StemArgs stem; PwArgs pw; DwArgs dw; PoolArgs pool; SepArgs sep; MbfArgs mbf; PwgArgs pwg; ChainArgs chain; SeFinishArgs se; XbfArgs xbf; SbfArgs sbf; LateArgs late; HeadsArgs heads;
+  StemArgs stem; PwArgs pw; DwArgs dw; PoolArgs pool; SepArgs sep; MbfArgs mbf; PwgArgs pwg; ChainArgs chain; SeFinishArgs se; XbfArgs xbf;
+#ifdef HEP_ALT          // the alternative library's three extra kernels (k_sbf.hip, k_late.hip, k_heads.hip)
+  SbfArgs sbf; LateArgs late; HeadsArgs heads;
+#endif
   std::vector<SepSeg> segs;         // host copy (device copy uploaded at build)
   std::vector<ChainNode> cnodes;    // host copy of a chain's node table
   std::vector<int> reads, writes;   // tensor ids
@@ -59,6 +63,7 @@ struct Op {
 
 struct Session {
   Arch arch; int size, max_batch, dtype, device; unsigned flags;
+  Knobs knobs;                      // the plan knobs of the environment this session was created in (hep_knobs.h)
   // The batch is cut into `lanes` contiguous slices of lane_batch frames; every lane owns an arena and a
   // patched copy of the plan, and the captured hipGraph runs the lanes as parallel branches: the
   // forward is a chain of ~100 small latency-bound kernels, and independent chains overlap on the chip.

@@ -28,6 +28,7 @@ struct StemArgs {
   int mfma;                                  // plan: 1 = stem_kernel (MFMA form), 0 = stem_valu_kernel (stem_uses_mfma() when the plan is built)
 };
 
+#ifdef HEP_ALT      // ---- the alternative library's kernels (make alt: k_sbf.hip, k_late.hip, k_heads.hip; measured losses / ties, NOTEBOOK.md) ----
 // ---- stem conv + block 0's depthwise conv as one launch (k_sbf.hip): the stem's output never reaches HBM ----
 struct SbfArgs {
   const float* in; int64_t sn, sc, sh, sw;      // the caller's fp32 input through its own element strides
@@ -42,6 +43,7 @@ struct SbfArgs {
 };
 void sbf_layout(SbfArgs* a);                     // fills tiles and the LDS layout from the shapes
 void launch_sbf(const SbfArgs&, hipStream_t);
+#endif
 
 // ---- pointwise conv as GEMM: out[M,N] = act((A[M,K] (*se)) . W[N,K]^T + bias) (+res) ----
 struct PwArgs {
@@ -143,9 +145,9 @@ int xbf_supports(int k, int s);                  // tile instantiations
 void xbf_tile(int k, int s, int* toh, int* tow);
 void launch_xbf(const XbfArgs&, hipStream_t);
 int xbf_prepare(void);
-int xbf_generic_forced(void);                 // HEP_XBF_GENERIC, read when a plan is built
 int xbf_specialised(const XbfArgs&);          // 1: a shape-specialised instantiation exists (names the device function)
 
+#ifdef HEP_ALT
 // ---- image-resident run of late MBConv blocks (k_late.hip): ONE workgroup per image runs several consecutive stride-1 blocks
 //      of the 8x8 maps back to back - expand 1x1 -> depthwise k x k -> squeeze-excite -> project 1x1 (+ residual) per block
 //      (efficientnet/model.py:69-104) - with block inputs / expanded tiles / squeeze-excite state in LDS and registers and every
@@ -213,6 +215,7 @@ int heads_fused_supported(int C, int depth, int bf16);
 int heads_lds_bytes(int depth, int* off_wdw);
 int heads_prepare(void);
 void launch_heads(const HeadsArgs&, hipStream_t);
+#endif   // HEP_ALT
 
 // ---- 3x3 s2 max-pool, TF-SAME with ZERO padding (utils_extra.py:72-86) ----
 struct PoolArgs { const void* in; void* out; int B, H, W, C, Ho, Wo, pad_t, pad_l, bf16; };
@@ -341,7 +344,7 @@ struct LossArgs {
 void launch_losses(const LossArgs&, hipStream_t);
 
 void launch_stem(const StemArgs&, hipStream_t);
-int stem_uses_mfma(int cout);      // which of the two stem kernels launch_stem picks (names the device function)
+int stem_uses_mfma(int cout, int force = -1);      // which of the two stem kernels the plan takes (force: Knobs::stem_mfma, -1 = by width)
 void launch_pw(const PwArgs&, hipStream_t);
 int pw_se_variant(const PwArgs&);   // 0 none, 1 shallow, 2 deep (template parameter of pw_gemm_kernel)
 void launch_pwg(const PwgArgs&, hipStream_t);

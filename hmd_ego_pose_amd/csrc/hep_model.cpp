@@ -13,6 +13,7 @@
 
 #include "hep.h"
 #include "hep_host.h"
+#include "hep_knobs.h"
 
 namespace hep {
 
@@ -238,7 +239,8 @@ struct Planner {
   Session* s; const Pack& pk; std::string* err; WBuilder wb; bool ok = true;
   std::vector<Ref> refs;
   int ntails = 0;                     // fused fronts that finish their squeeze-excite in their tail (one counter block each)
-  Planner(Session* s_, const Pack& p, std::string* e) : s(s_), pk(p), err(e) { wb.dtype = s_->dtype; }
+  const Knobs kn;                     // plan knobs as the environment had them when the session was created (hep_knobs.h)
+  Planner(Session* s_, const Pack& p, std::string* e) : s(s_), pk(p), err(e), kn(s_->knobs) { wb.dtype = s_->dtype; }
 
   int tensor(const std::string& name, int H, int W, int C, bool f32 = false) {
     TensorDesc t; t.name = name; t.H = H; t.W = W; t.C = C; t.f32 = f32;
@@ -260,7 +262,10 @@ struct Planner {
   }
   int new_op(OpKind k, const std::string& name) {
     Op o; memset(&o.stem, 0, sizeof o.stem); memset(&o.pw, 0, sizeof o.pw); memset(&o.dw, 0, sizeof o.dw);
-    memset(&o.pool, 0, sizeof o.pool); memset(&o.sep, 0, sizeof o.sep); memset(&o.mbf, 0, sizeof o.mbf); memset(&o.pwg, 0, sizeof o.pwg); memset(&o.chain, 0, sizeof o.chain); memset(&o.se, 0, sizeof o.se); memset(&o.xbf, 0, sizeof o.xbf); memset(&o.sbf, 0, sizeof o.sbf); memset(&o.late, 0, sizeof o.late); memset(&o.heads, 0, sizeof o.heads);
+    memset(&o.pool, 0, sizeof o.pool); memset(&o.sep, 0, sizeof o.sep); memset(&o.mbf, 0, sizeof o.mbf); memset(&o.pwg, 0, sizeof o.pwg); memset(&o.chain, 0, sizeof o.chain); memset(&o.se, 0, sizeof o.se); memset(&o.xbf, 0, sizeof o.xbf);
+#ifdef HEP_ALT
+    memset(&o.sbf, 0, sizeof o.sbf); memset(&o.late, 0, sizeof o.late); memset(&o.heads, 0, sizeof o.heads);
+#endif
     o.kind = k; o.name = name;
     s->ops.push_back(o);
     return (int)s->ops.size() - 1;
@@ -298,24 +303,23 @@ struct Planner {
         pmode = 0; pNT = (tilesN + chunks - 1) / chunks;
         pMT = (Mmax >= 65536 && pNT <= 4) ? 2 : 1;
       } else if (ksteps >= 8) {     // small maps, deep K (project): split K over the 4 waves
-        // widest split-K tile (HEP_PW_NT2, A/B knob).  Measured at phi 0 b16 (two m-tiles per wave): 4 / 2 / 1 n-tiles ->
+        // widest split-K tile (alt build: HEP_PW_NT2).  Measured at phi 0 b16 (two m-tiles per wave): 4 / 2 / 1 n-tiles ->
         // one batch 0.6312 / 0.6259 / 0.6360 ms, four in flight 48.2k / 48.3k / 47.0k frames/s: 2
-        const int nt2_max = getenv("HEP_PW_NT2") ? atoi(getenv("HEP_PW_NT2")) : 2;
+        const int nt2_max = kn.pw_nt2;
         pmode = 2; pMT = 1; pNT = clampi(strips * tilesN / 256, 1, std::min(std::min(8, nt2_max), tilesN));
       } else {                      // small maps, wide N (expand / lateral): waves side by side in N
         pmode = 1; pMT = 1; pNT = clampi(strips * tilesN / (4 * 256), 1, std::min(8, (tilesN + 3) / 4));
       }
       // Two m-tiles per wave in modes 1/2 (every weight fragment feeds two MFMAs, half the weight re-reads
       // from L2): no effect on a single batch in flight, but -2.5 % on the step with 4 batches in flight and
-      // at batch 64, where these layers are bound by L2 traffic and not by latency.  HEP_PW_MT2=0 disables.
+      // at batch 64, where these layers are bound by L2 traffic and not by latency.  (alt build: HEP_PW_MT2=0 disables.)
       {
-        const char* e = getenv("HEP_PW_MT2");
-        if (pmode != 0 && strips >= 8 && !(e && atoi(e) == 0)) { pMT = 2; pNT = std::min(pNT, 4); }
-        if (pmode == 2) pNT = std::min(pNT, std::max(1, getenv("HEP_PW_NT2") ? atoi(getenv("HEP_PW_NT2")) : 2));
+        if (pmode != 0 && strips >= 8 && kn.pw_mt2 != 0) { pMT = 2; pNT = std::min(pNT, 4); }
+        if (pmode == 2) pNT = std::min(pNT, std::max(1, kn.pw_nt2));
         // fp32 sessions: one more n-tile per wave where that brings the launch from two rounds of workgroups to one (the last
         // project conv of phi 0: 1152 -> 320 on the 8x8 maps, 32 x 10 = 320 workgroups with two n-tiles, 32 x 7 = 224 with three:
-        // fp32 one batch -5 us; bf16 -2 us = inside the run-to-run spread, its plan stays as it was).  HEP_PW_NT3=0 / 1 overrides.
-        if (pmode == 2 && (getenv("HEP_PW_NT3") ? atoi(getenv("HEP_PW_NT3")) != 0 : s->dtype == 0)) {
+        // fp32 one batch -5 us; bf16 -2 us = inside the run-to-run spread, its plan stays as it was).  (alt build: HEP_PW_NT3=0 / 1 overrides.)
+        if (pmode == 2 && (kn.pw_nt3 >= 0 ? kn.pw_nt3 != 0 : s->dtype == 0)) {
           const int64_t mblocks = (strips + pMT - 1) / pMT;
           auto wgs = [&](int nt) { return mblocks * ((tilesN + nt - 1) / nt); };
           if (wgs(pNT) > 256 && wgs(pNT) <= 512 && pNT < 8 && wgs(pNT + 1) <= 256) pNT++;
@@ -332,14 +336,15 @@ struct Planner {
     if (se) {
       const int rows_wg = pmode == 0 ? 64 * pMT : 16 * pMT, per_n = pmode == 1 ? 4 * pNT : pNT;
       const double wgs = (double)((Mmax + rows_wg - 1) / rows_wg) * ((tilesN + per_n - 1) / per_n);
-      const double maxmb = getenv("HEP_SE_MAXMB") ? atof(getenv("HEP_SE_MAXMB")) : 4.0;      // (plain getenv: the plan is built once per session)
+      const double maxmb = kn.se_maxmb;
+#ifdef HEP_ALT
       // ... or no launch at all (HEP_SE_TAIL=1, NOT the default): the fused front that produced the partial rows finishes it in its tail
       // (k_mbf.hip: last workgroup of an image to arrive).  Measured, round 5, phi 0 b16: 59 -> 49 launches, bit-identical, four in flight
       // 51.4k against 51.3k frames/s, one batch 0.600 -> 0.605 ms, fp32 one batch 0.980 -> 1.021 ms, phi 3 one batch +2.3 %: the tail
       // (stores acknowledged, ticket, rows and weight rows fetched past L2 by ONE workgroup) costs 6-9 us against the ~5 us of a launch
       // and its boundary - the price list's "5-13 us per seam inside a launch" again.
       int tail_op = -1;
-      if (getenv("HEP_SE_TAIL") && atoi(getenv("HEP_SE_TAIL")) != 0)
+      if (kn.se_tail != 0)
         for (const Ref& r : refs) if (r.field == F_MBF_PART && r.tensor == se->hpart_t) tail_op = r.op;
       if (wgs * K * se->sqp * es() > maxmb * 1e6 && tail_op >= 0 && ntails < 64) {
         scale_t = tensor(name + ".se_scale", 1, 1, K, true);
@@ -351,7 +356,9 @@ struct Planner {
         s->ops[tail_op].name += "+se";      // (the launch list shows which fronts carry the finish)
         s->ops[tail_op].weight_bytes += (double)K * se->sq * es() + ((double)K + se->sq) * 4;
         s->ops[tail_op].flops_per_image += 2.0 * K * se->sq;
-      } else if (wgs * K * se->sqp * es() > maxmb * 1e6) {
+      } else
+#endif
+      if (wgs * K * se->sqp * es() > maxmb * 1e6) {
         scale_t = tensor(name + ".se_scale", 1, 1, K, true);
         const int sop = new_op(OP_SE, name.substr(0, name.find('.')) + ".se");
         Op& so = s->ops[sop];
@@ -368,7 +375,7 @@ struct Planner {
     o.pw.K = K; o.pw.N = N; o.pw.tilesN = tilesN; o.pw.HW = HW; o.pw.act = act; o.pw.bf16 = s->dtype;
     o.pw.mode = pmode; o.pw.MT = pMT; o.pw.NT = pNT;
     // fp32 split-K GEMMs deep enough for eight K slices of two load batches each (HEP_PW_W8=0: four waves as before)
-    o.pw.nwv = (s->dtype == 0 && pmode == 2 && pNT <= 2 && K >= (getenv("HEP_PW_W8_MINK") ? atoi(getenv("HEP_PW_W8_MINK")) : 512) && !(getenv("HEP_PW_W8") && atoi(getenv("HEP_PW_W8")) == 0)) ? 8 : 4;
+    o.pw.nwv = (s->dtype == 0 && pmode == 2 && pNT <= 2 && K >= kn.pw_w8_mink && kn.pw_w8 != 0) ? 8 : 4;
     tref(op, F_PW_A, in_t, false); tref(op, F_PW_OUT, out_t, true);     // (reads[0] is the GEMM's activation operand: fp8 calibration)
     if (quant && s->dtype == 2) {     // fp8 session: e4m3 weights, one scale per output channel behind the BN fold
       std::vector<float> sc;
@@ -380,7 +387,7 @@ struct Planner {
       int producer = -1;
       for (const Ref& r : refs) if (r.field == F_MBF_OUT && r.tensor == in_t) producer = r.op;
       const bool frag = s->dtype != 2 && !quant_fp8 && pmode == 2 && pMT == 2 && pNT <= 4 && act != ACT_SWISH && se && HW % 16 == 0 && producer >= 0 &&
-                        !(getenv("HEP_PW_FRAG") && atoi(getenv("HEP_PW_FRAG")) == 0);
+                        kn.pw_frag != 0;
       if (frag) {
         const int kstep = s->dtype ? 32 : 16, klane = s->dtype ? 8 : 4, kst = (K + kstep - 1) / kstep;
         std::vector<float> wfr((size_t)tilesN * kst * 64 * klane, 0.f);      // K padded to whole k-steps with zeros
@@ -468,9 +475,8 @@ struct Planner {
   // boundary launch: [SE + project of the deferred block] + [expand + depthwise + SE partial sums of block i] (k_xbf.hip)
   bool try_xbf(int i, const MBConv& b, int dw_t, const std::vector<float>& wdw, const std::vector<float>& bdw, size_t wr_off, int sqp2,
                int Hin, int Win, int Ho, int Wo, int pt, int pl, bool mid_needed, int* part_t, int* nblk) {
-    const int minh = getenv("HEP_XBF_MINH") ? atoi(getenv("HEP_XBF_MINH")) : 64;     // smallest input map that takes the boundary kernel
-    const char* e = getenv("HEP_XBF");
-    if (e && atoi(e) == 0) return false;
+    const int minh = kn.xbf_minh;     // smallest input map that takes the boundary kernel (64; alt build: HEP_XBF_MINH, HEP_XBF=0)
+    if (kn.xbf == 0) return false;
     const MBConv& pb = defer.b;
     if (s->dtype == 2 || !b.expand || Hin < minh || !xbf_supports(b.k, b.stride) || pb.cout > 16 * XBF_MAXNT1 || b.cexp % 16 != 0 || pb.cexp % 8 != 0 ||
         (defer.se.sqp != 8 && defer.se.sqp != 16) || pb.cexp > 512) return false;
@@ -478,7 +484,7 @@ struct Planner {
     xa.H = Hin; xa.W = Win; xa.K1 = pb.cexp; xa.N1 = pb.cout; xa.NT1 = (pb.cout + 15) / 16; xa.Cexp = b.cexp; xa.NT2 = b.cexp / 16;
     xa.Ho = Ho; xa.Wo = Wo; xa.k = b.k; xa.s = b.stride; xa.pad_t = pt; xa.pad_l = pl; xa.bf16 = s->dtype;
     xa.se_rows = defer.se.rows; xa.sq = defer.se.sq; xa.sqp = defer.se.sqp; xa.inv_hw = defer.se.inv_hw; xa.sq2 = b.se; xa.sqp2 = sqp2;
-    xa.generic = xbf_generic_forced();
+    xa.generic = kn.xbf_generic != 0;
     if (xbf_layout(&xa) == 0) return false;
     xa.tiles_x = (Wo + xa.tow - 1) / xa.tow; xa.tiles = xa.tiles_x * ((Ho + xa.toh - 1) / xa.toh);
     // weights: project of the deferred block (BN2 folded), expand of this block (BN0 folded), depthwise (BN1 folded, by the caller)
@@ -517,7 +523,7 @@ struct Planner {
     {
       // default: two tiles per workgroup where one tile per workgroup would need more than the 512 workgroups the GPU holds at
       // once (two per CU) - the second round then runs in the same workgroups, without their blob / squeeze-excite prologue
-      const int tpw_env = getenv("HEP_XBF_TPW") ? atoi(getenv("HEP_XBF_TPW")) : 0;
+      const int tpw_env = kn.xbf_tpw;
       const int tpw = tpw_env > 0 ? tpw_env : ((int64_t)xa.tiles * s->lane_batch > 512 ? 2 : 1);
       xa.tpw = std::max(1, std::min(tpw, xa.tiles));
     }
@@ -567,9 +573,9 @@ struct Planner {
     // output tile side of the fused front: 16 on the stride-1 layers of 16x16 / 32x32 maps (the whole 16x16 map per
     // workgroup: no halo re-expansion, a quarter of the workgroups and of their fixed staging / drain latency), else 8.
     // HEP_MBF_TS=8 forces the small tile (A/B measurements, parity test of the alternative plan).
-    const int ts16_maxh = getenv("HEP_MBF_TS16_MAXH") ? atoi(getenv("HEP_MBF_TS16_MAXH")) : 32;     // A/B knob
+    const int ts16_maxh = kn.mbf_ts16_maxh;     // 32 (alt build: A/B knob)
     int ts = (b.stride == 1 && b.expand && Ho >= 16 && Ho <= ts16_maxh) ? 16 : 8;
-    if (const char* e = getenv("HEP_MBF_TS")) if (atoi(e) == 8) ts = 8;
+    if (kn.mbf_ts8) ts = 8;
     int max_in = mbf_max_inside(Hin, Win, b.k, b.stride, pt, pl, ts);   // rows of the compact input tile in LDS
     if (ts == 16 && mbf_lds_layout(b.cin, 64, b.k, b.stride, s->dtype, b.expand, max_in, ts, nullptr) > 159 * 1024 &&
         mbf_lds_layout(b.cin, 32, b.k, b.stride, s->dtype, b.expand, max_in, ts, nullptr) > 159 * 1024) {
@@ -580,10 +586,9 @@ struct Planner {
     // maps up to 32x32 (it expands only the tile pixels inside the image, so on the 8x8 maps the halo costs
     // nothing) and loses on the big early maps (bandwidth-bound, the two-kernel path already streams well;
     // stride-2 halos there cost up to 4.5x recompute).  HEP_MBF=all|none overrides for A/B runs.
-    const char* mode = getenv("HEP_MBF");
-    const int maxh = getenv("HEP_MBF_MAXH") ? atoi(getenv("HEP_MBF_MAXH")) : 32;     // A/B knob: largest input map that takes the fused front
-    const bool want = mode ? !strcmp(mode, "all") : Hin <= maxh;
-    if (want && !(mode && !strcmp(mode, "none")))
+    const int maxh = kn.mbf_maxh;     // largest input map that takes the fused front (32)
+    const bool want = kn.mbf >= 0 ? kn.mbf == 1 : Hin <= maxh;
+    if (want)
       for (int cand : {64, 32, 16})
         if (mbf_lds_layout(b.cin, std::min(cand, b.expand ? cand : b.cexp), b.k, b.stride, s->dtype, b.expand, max_in, ts, nullptr) <= 159 * 1024) { CC = cand; break; }
     // The tile / channel chunk / K-slice plan with the fewest ROUNDS of workgroups (HEP_MBF_MP=0 disables, =2 lifts the bf16
@@ -592,14 +597,13 @@ struct Planner {
     // of 146 KB per CU where 288 want to be resident (two rounds).  The multi-pass expand (k_mbf.hip, MP) stages K in slices and
     // gives fp32 the workgroup counts of the bf16 plan.
     {
-      const char* e = getenv("HEP_MBF_MP");
-      const bool force = e && !strcmp(e, "force");                  // parity runs: the multi-pass form wherever it exists, whatever the rounds
-      const bool mp_on = e ? (force || atoi(e) != 0) : true;
+      const bool force = kn.mbf_mp == 3;                             // parity runs: the multi-pass form wherever it exists, whatever the rounds
+      const bool mp_on = kn.mbf_mp != 0;
       // A pass costs ~1 us of phase changes and the wider chunk a longer depthwise phase, so one round saved out of three does not
       // pay (phi 3 blocks 9-12, bf16: 3 -> 2 rounds, 23.6 -> 26.4 us): the multi-pass plan must at least HALVE the rounds.  bf16
       // sessions additionally keep plans of up to two rounds (HEP_MBF_MP=2 lifts that): measured only where the gain is large -
       // phi 3 @ 512 b8 blocks 14-17 (7 -> 2 rounds) 47 -> 38 us, blocks 19-23 26.5 -> 18.9 us, 4.65k -> 4.87k frames/s.
-      const long min_old_rounds = (s->dtype == 0 || (e && atoi(e) == 2)) ? 2 : 3;
+      const long min_old_rounds = (s->dtype == 0 || kn.mbf_mp == 2) ? 2 : 3;
       if (CC && b.expand && mp_on && s->dtype != 2) {
         struct Cand { int ts, CC, npass, kp; long rounds; size_t lds; };
         const int kstep = s->dtype ? 32 : 16, ksteps = (b.cin + kstep - 1) / kstep;
@@ -609,7 +613,7 @@ struct Planner {
           return (wgs + 256 * per_cu - 1) / (256 * per_cu);
         };
         Cand best{ts, CC, 1, 0, rounds_of(ts, CC, mbf_lds_layout(b.cin, CC, b.k, b.stride, s->dtype, 1, max_in, ts, nullptr)), 0};
-        const bool ts16_ok = b.stride == 1 && Ho >= 16 && Ho <= ts16_maxh && !(getenv("HEP_MBF_TS") && atoi(getenv("HEP_MBF_TS")) == 8);
+        const bool ts16_ok = b.stride == 1 && Ho >= 16 && Ho <= ts16_maxh && !kn.mbf_ts8;
         for (int ts_ : {16, 8}) {
           if (ts_ == 16 && !ts16_ok) continue;
           const int mi = mbf_max_inside(Hin, Win, b.k, b.stride, pt, pl, ts_);
@@ -626,7 +630,7 @@ struct Planner {
             }
         }
         if (best.npass > 1) { ts = best.ts; CC = best.CC; npass = best.npass; kp = best.kp; max_in = mbf_max_inside(Hin, Win, b.k, b.stride, pt, pl, ts); }
-        if (getenv("HEP_PLAN_DEBUG")) fprintf(stderr, "libhep plan: block %d front: tile %d, %d channels per workgroup, %d pass(es) of %d input channels, %ld round(s)\n", i, ts, CC, npass, kp ? kp : b.cin, best.rounds);
+        if (kn.plan_debug) fprintf(stderr, "libhep plan: block %d front: tile %d, %d channels per workgroup, %d pass(es) of %d input channels, %ld round(s)\n", i, ts, CC, npass, kp ? kp : b.cin, best.rounds);
       }
     }
     // squeeze-excite weights: reduce FC [sq][Cexp] (fp32) for the front kernel; bias, expand FC [Cexp][sqp] (session
@@ -671,7 +675,7 @@ struct Planner {
       // (the register-resident form - the whole tile requested at kernel start, parked slice by slice - measured SLOWER than fetching
       //  slice by slice: 8x8 maps 24.1 us against 22.4 us per launch, blocks 9 / 10 31.4 against 29.6: a pass is not bound by its
       //  memory round trip but by its three phase changes, ~1 us per pass whatever feeds it; HEP_MBF_MP_RES=1 selects it)
-      m.mp_resident = npass > 1 && mbf_mp_resident(b.cin, CC, max_in, ts) && getenv("HEP_MBF_MP_RES") && atoi(getenv("HEP_MBF_MP_RES")) != 0;
+      m.mp_resident = npass > 1 && mbf_mp_resident(b.cin, CC, max_in, ts) && kn.mbf_mp_res != 0;
       mbf_lds_layout(b.cin, CC, b.k, b.stride, s->dtype, b.expand, max_in, ts, &m, kp);
       wref(op, F_MBF_WR, wr_off);
       if (b.expand) {
@@ -703,10 +707,10 @@ struct Planner {
       // depthwise on its own: from global memory for the big maps (bandwidth-bound, k_dw.hip), through
       // LDS (the fused kernel without its expand stage) on the 8x8 maps, where the global-memory
       // version is a chain of k*k dependent load latencies.  HEP_DWLDS=0|1 overrides.
-      const char* dl = getenv("HEP_DWLDS");
+      const int dl = kn.dwlds;
       // (measured at bs16: the 5x5 stride-2 layer on the 64x64 map takes 20.6 us through LDS against
       //  27.2 us from global memory - 25 taps per output re-read too much through L1)
-      const bool lds_dw = dl ? atoi(dl) != 0 : (Hin <= 8 || (b.k == 5 && Hin <= 64));
+      const bool lds_dw = dl >= 0 ? dl != 0 : (Hin <= 8 || (b.k == 5 && Hin <= 64));
       const int ccl = std::min(64, b.cexp);
       const int max_in8 = mbf_max_inside(Hin, Win, b.k, b.stride, pt, pl, 8);
       if (lds_dw && mbf_lds_layout(b.cexp, ccl, b.k, b.stride, s->dtype, 0, max_in8, 8, nullptr) <= 159 * 1024) {
@@ -727,6 +731,7 @@ struct Planner {
         o.weight_bytes = (double)b.k * b.k * b.cexp * 4;
         o.flops_per_image = 2.0 * b.k * b.k * Ho * Wo * b.cexp;
       } else {
+#ifdef HEP_ALT
         if (i == 0 && fstem.on) {
           // stem conv + this depthwise conv as ONE launch (k_sbf.hip): the stem's output stays in LDS
           const int op = new_op(OP_SBF, "stem+b0.dw");
@@ -745,7 +750,9 @@ struct Planner {
           o.act_bytes_per_image = 3.0 * fstem.S * fstem.S * 4 + (double)Ho * Wo * b.cexp * es() + (double)nblk * sqp * 4;
           o.weight_bytes = (27.0 + 10.0) * b.cexp * 4;
           o.flops_per_image = 2.0 * 27 * Hin * Win * b.cexp + 2.0 * 9 * Ho * Wo * b.cexp;
-        } else {
+        } else
+#endif
+        {
         // strip width: 4 output pixels per lane on the big maps; the stride-2 layers read 2x the columns per
         // output, so 2 keeps their loads denser (measured 18.1 us against 19.8 us on 128x128 -> 64x64 x 96)
         const int TW = Wo >= 32 ? (b.stride == 2 ? 2 : 4) : (Wo >= 16 ? 2 : 1);
@@ -774,12 +781,12 @@ struct Planner {
     return defer.out_t;
   }
 
+#ifdef HEP_ALT
   // ---- image-resident run of late blocks (k_late.hip): blocks i0 .. i1 as ONE launch, one workgroup per image ----
   // how many blocks starting at i0 (input map H x W, bf16 sessions) the late kernel can take: 0 = none
   int late_run(const std::vector<MBConv>& blocks, int i0, int H, int W) const {
     // HEP_LATE: 0 = launch by launch (front / squeeze-excite / project per block), 1 = the image-resident kernel
-    const char* e = getenv("HEP_LATE");
-    if (!(e ? atoi(e) != 0 : late_default()) || s->dtype != 1) return 0;
+    if (!kn.late || s->dtype != 1) return 0;
     int n = 0;
     for (size_t i = i0; i < blocks.size() && n < LATE_MAX_BLOCKS; i++, n++) {
       const MBConv& b = blocks[i];
@@ -791,7 +798,6 @@ struct Planner {
     for (int j = 0; j < n; j++) { const MBConv& b = blocks[i0 + j]; probe.blk[j].Cin = b.cin; probe.blk[j].Cexp = b.cexp; probe.blk[j].N = b.cout; probe.blk[j].k = b.k; }
     return late_layout(&probe) ? n : 0;
   }
-  static bool late_default() { return false; }
   // returns the output tensors of the blocks
   std::vector<int> add_late(const std::vector<MBConv>& blocks, int i0, int n, int x) {
     std::vector<int> outs;
@@ -873,11 +879,19 @@ struct Planner {
     memcpy(wb.host.data() + boff, blob.data(), blob.size());
     // workgroups per image (HEP_LATE_G; default 3 where every block's chunk count divides): each runs 1 / G of the chunk loop -
     // the part that is bound by ONE CU's vector ALU - and they meet once per block (k_late.hip)
-    int G = getenv("HEP_LATE_G") ? atoi(getenv("HEP_LATE_G")) : 3;
+    int G = kn.late_g;
     if (G < 1 || G > 8) G = 1;
     for (int j = 0; j < n; j++) if (la.blk[j].nchunks % G != 0) G = 1;
+    // the members of a group spin-wait for each other: they must all be resident at once.  A workgroup of this kernel fills a CU (1024
+    // threads, near-full LDS), so a launch of lane_batch * G workgroups is only safe while that is a small part of the chip - other
+    // streams' workgroups hold CUs as well.  Beyond a quarter of the CUs: one workgroup per image, no meetings.
+    {
+      int cus = 0;
+      if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, s->device) != hipSuccess || cus <= 0) cus = 256;
+      if ((long)s->lane_batch * G > cus / 4) G = 1;
+    }
     la.G = G;
-    la.cross_xcd = getenv("HEP_LATE_XCD") && atoi(getenv("HEP_LATE_XCD")) != 0;      // 1: a group on consecutive workgroup ids = across XCDs (tests: same bits)
+    la.cross_xcd = kn.late_xcd != 0;      // 1: a group on consecutive workgroup ids = across XCDs (tests: same bits)
     const int ds_t = tensor(std::string(nm) + ".dw", 1, 1, 64 * cexp_max * (G > 1 ? 2 : 1));
     la.dstride = 64 * cexp_max * 2 * (G > 1 ? 2 : 1);
     const int hp_t = tensor(std::string(nm) + ".se_part", 1, 1, 2 * 8 * 64, true);
@@ -894,6 +908,8 @@ struct Planner {
     o.flops_per_image = flops;
     return outs;
   }
+
+#endif   // HEP_ALT
 
   // ---- fused separable conv launch (1..n segments sharing C) ----
   struct SegSpec {
@@ -926,8 +942,7 @@ struct Planner {
     // wave-per-patch kernel of k_tower.hip; HEP_TOWER=0 keeps them on the tiled kernel of k_sep.hip
     int direct = 0;
     {
-      const char* e = getenv("HEP_TOWER");
-      bool simple = specs.size() > 1 && !chain && tower_supports(C) && !(e && atoi(e) == 0);
+      bool simple = specs.size() > 1 && !chain && tower_supports(C) && kn.tower != 0;
       bool maps = true, heads = true;
       for (const SegSpec& sp : specs) {
         simple = simple && sp.nsrc == 1 && sp.kind[0] == SRC_SAME && !sp.pre_act && sp.fw[0] == 1.f;
@@ -941,8 +956,7 @@ struct Planner {
     // HEP_TOWER_COOP: 0 off, 1 on wherever instantiated, 2 map layers only, 3 headers only
     int coop = 0;
     if (direct && tower_coop_supported(C, s->dtype != 0)) {
-      const char* e = getenv("HEP_TOWER_COOP");
-      const int v = e ? atoi(e) : -1;
+      const int v = kn.tower_coop;
       if (v < 0) coop = s->dtype == 0 || (C >= 160 ? direct == 1 : tower_coop_default_bf16_64(direct));
       else coop = v == 1 || (v == 2 && direct == 1) || (v == 3 && direct == 2);
     }
@@ -987,7 +1001,7 @@ struct Planner {
         }
         sg.N = Nc; sg.tilesN = tilesN; sg.act = sp.act; sg.n_base = n0;
         sg.ts = ts_pick;   // 8; 16x16 tiles measured slower (3 dependent gather rounds per lane, 1 workgroup per CU)
-        if (const char* e = getenv("HEP_SEP_TS4_MAXHW")) if (!direct && !chain && specs.size() == 1 && hw <= atoi(e)) sg.ts = 4;   // latency knob: 4x4 tiles on levels with few 8x8 tiles (one batch in flight +1-3 %, four in flight -1-4 %: DESIGN section 2)
+        if (!direct && !chain && specs.size() == 1 && hw <= kn.sep_ts4_maxhw) sg.ts = 4;   // latency knob: 4x4 tiles on levels with few 8x8 tiles (one batch in flight +1-3 %, four in flight -1-4 %: DESIGN section 2)
         ts_max = std::max(ts_max, sg.ts);
         if (sp.out_t >= 0) cols_map = std::max(cols_map, Nc); else cols_f32 = std::max(cols_f32, Nc);
         sg.tiles_x = (hw + sg.ts - 1) / sg.ts; sg.tiles_y = sg.tiles_x; sg.tile_begin = tile_begin; sg.tiles_x_rcp = rcp_u32(sg.tiles_x);
@@ -1014,12 +1028,13 @@ struct Planner {
     o.sep.coop = coop;
     bool all_maps = true;
     for (const SegSpec& sp : specs) all_maps = all_maps && sp.out_t >= 0 && sp.N == C;
-    sep_lds_layout(C, s->dtype, ts_max, cols_f32, cols_map, &o.sep, (chain || specs.size() == 1) && all_maps && !direct && !(getenv("HEP_SEP_WLDS") && atoi(getenv("HEP_SEP_WLDS")) == 0));
+    sep_lds_layout(C, s->dtype, ts_max, cols_f32, cols_map, &o.sep, (chain || specs.size() == 1) && all_maps && !direct && kn.sep_wlds != 0);
     if (direct) { o.sep.off_wdw = 0; o.sep.off_bias = (size_t)9 * C * 4; o.sep.lds_bytes = o.sep.off_bias + (size_t)tiles_n_max * 16 * 4; }
     if (o.sep.lds_bytes > 160 * 1024) { *err = "BiFPN width too large for the fused separable-conv tile"; ok = false; return; }
     o.act_bytes_per_image = bytes; o.flops_per_image = flops; o.weight_bytes = wbytes;
   }
 
+#ifdef HEP_ALT
   // ---- the five head towers depth-first (k_heads.hip): ONE launch for the tower layers and headers of every net and level ----
   struct HeaderSpec { int net; std::string key; int kin, kout, off, out, act; };
   bool add_heads_fused(const std::vector<std::string>& nets, const std::vector<HeaderSpec>& hds, const int feat[5], int depth) {
@@ -1133,6 +1148,8 @@ struct Planner {
     return true;
   }
 
+#endif   // HEP_ALT
+
   // ---- LDS-resident chain of small-level BiFPN nodes (k_chain.hip): [optional max-pools of cell 0] + nodes ----
   // pools: {source tensor, output tensor, output level} in order (cell 0: p6_in from p6_pre, p7_in from p6_in).
   // Returns false (nothing added) when the chain does not fit the kernel: the caller then emits the k_sep.hip path.
@@ -1140,7 +1157,7 @@ struct Planner {
   bool add_chain(const std::string& name, const std::vector<PoolSpec>& pools, const std::vector<SegSpec>& specs) {
     const int C = s->arch.fpn_w;
     if (C % 8 != 0 || specs.empty()) return false;
-    if (const char* e = getenv("HEP_CHAIN_F32")) if (s->dtype == 0 && atoi(e) == 0) return false;      // A/B knob: fp32 chains back on k_sep.hip
+    if (s->dtype == 0 && kn.chain_f32 == 0) return false;      // (alt build A/B knob: fp32 chains back on k_sep.hip)
     // LDS map slots.  Every slot records who writes it (def: -1 = the prologue, else the node index) and the last node that
     // reads it; after the node list is complete the slots are packed by liveness (pack_slots below): the output of node n takes
     // the place of a map of the same size whose last reader is a node <= n.  fp32 sessions need it (maps of 16 KB), bf16
@@ -1272,9 +1289,9 @@ struct Planner {
     auto wlds = [&](int mode) { return mode == 2 ? (size_t)nconv * wsmall : (size_t)(mode == 1 ? std::min(2, nconv) : nconv) * wnode_bytes; };
     ca.stream_w = 0;
     while (ca.stream_w < 2 && ca.off_w + wlds(ca.stream_w) + halo_b + atile_b > 158 * 1024) ca.stream_w++;
-    if (const char* e = getenv("HEP_CHAIN_STREAM")) ca.stream_w = std::max(0, std::min(2, atoi(e)));     // A/B knob, parity tests of the other forms in bf16
+    if (kn.chain_stream >= 0) ca.stream_w = std::min(2, kn.chain_stream);     // A/B knob, parity tests of the other forms in bf16
     if (ca.stream_w == 2 && (C + (s->dtype ? 31 : 15)) / (s->dtype ? 32 : 16) > 6) return false;         // six k-steps of fragments in registers
-    if (ca.stream_w == 2 && getenv("HEP_CHAIN_WGLOBAL") && atoi(getenv("HEP_CHAIN_WGLOBAL")) == 0) return false;
+    if (ca.stream_w == 2 && kn.chain_wglobal == 0) return false;
     ca.off_halo = ca.off_w + wlds(ca.stream_w);
     ca.off_atile = ca.off_halo + halo_b;
     ca.lds_bytes = ca.off_atile + atile_b;
@@ -1334,20 +1351,22 @@ int build_session(Session* s, const Pack& pack, std::string* err) {
         for (int t = 0; t < 9; t++) wf[((size_t)t * 3 + ci) * A.stem + co] = w->data[((size_t)co * 3 + ci) * 9 + t] * bn.scale[co];
     x = P.tensor("stem", H, W, A.stem);
     int pt, pb, pl, pr; same_pad(S, 3, 2, &pt, &pb); same_pad(S, 3, 2, &pl, &pr);
+#ifdef HEP_ALT
     // stem + block 0's depthwise conv as one launch (k_sbf.hip), possible when block 0 has no expand conv (every
     // EfficientNet-B0..B7).  NOT the default: measured at phi 0 b16 bf16 the fused launch takes 42.8 us against 14.5 + 16.0 us
     // for the two kernels (workgroup life 14.8 us: 4 us input staging, 6.3 us for the stem phase - instruction-bound, not
     // matrix-pipe-bound: the split-bf16 MFMA form changed nothing - 2 us depthwise, 1.9 us channel sums; 14x14 tiles
     // recompute 1.56x the stem pixels).  HEP_SBF=1 selects it (parity-tested as an alternative plan).
     const MBConv& b0 = A.blocks[0];
-    const char* esbf = getenv("HEP_SBF");
-    if ((esbf && atoi(esbf) != 0) && s->dtype != 2 && !b0.expand && b0.k == 3 && b0.stride == 1 && A.stem % 8 == 0 && A.stem <= 64 && b0.cexp == A.stem &&
+    if (P.kn.sbf != 0 && s->dtype != 2 && !b0.expand && b0.k == 3 && b0.stride == 1 && A.stem % 8 == 0 && A.stem <= 64 && b0.cexp == A.stem &&
         b0.se <= 16) {
       P.fstem.on = true; P.fstem.w_off = P.wb.put_f32(wf); P.fstem.b_off = P.wb.put_f32(bn.shift); P.fstem.S = S; P.fstem.pad_t = pt; P.fstem.pad_l = pl; P.fstem.stem_t = x;
-    } else {
+    } else
+#endif
+    {
     const int op = P.new_op(OP_STEM, "stem");
     Op& o = s->ops[op];
-    o.stem.H = S; o.stem.W = S; o.stem.Ho = H; o.stem.Wo = W; o.stem.Cout = A.stem; o.stem.pad_t = pt; o.stem.pad_l = pl; o.stem.bf16 = s->dtype; o.stem.mfma = stem_uses_mfma(A.stem);
+    o.stem.H = S; o.stem.W = S; o.stem.Ho = H; o.stem.Wo = W; o.stem.Cout = A.stem; o.stem.pad_t = pt; o.stem.pad_l = pl; o.stem.bf16 = s->dtype; o.stem.mfma = stem_uses_mfma(A.stem, P.kn.stem_mfma);
     P.wref(op, F_STEM_W, P.wb.put_f32(wf)); P.wref(op, F_STEM_B, P.wb.put_f32(bn.shift));
     P.tref(op, F_STEM_OUT, x, true);
     o.act_bytes_per_image = 3.0 * S * S * 4 + (double)H * W * A.stem * P.es();
@@ -1358,6 +1377,7 @@ int build_session(Session* s, const Pack& pack, std::string* err) {
   int taps[3] = {-1, -1, -1};
   for (int t = 0; t < 3; t++) P.tap_blocks.push_back(A.taps[t]);
   for (size_t i = 0; i < A.blocks.size(); i++) {
+#ifdef HEP_ALT
     if (const int nl = P.late_run(A.blocks, (int)i, H, W)) {        // blocks i .. i + nl - 1 as one image-resident launch (k_late.hip)
       const std::vector<int> outs = P.add_late(A.blocks, (int)i, nl, x);
       if (!P.ok || (int)outs.size() != nl) return HEP_ERR_PACK;
@@ -1367,6 +1387,7 @@ int build_session(Session* s, const Pack& pack, std::string* err) {
       i += nl - 1;
       continue;
     }
+#endif
     x = P.add_mbconv((int)i, A.blocks[i], x, &H, &W);
     if (!P.ok) return HEP_ERR_PACK;
     for (int t = 0; t < 3; t++) if (A.taps[t] == (int)i) taps[t] = x;
@@ -1380,7 +1401,7 @@ int build_session(Session* s, const Pack& pack, std::string* err) {
   std::vector<Planner::PoolSpec> pending_pools;                                      // cell 0's two max-pools ride in the first chain
   // HEP_CHAIN: 0 = every node its own launch, 1 = chains inside k_sep.hip (mode 2), 2 (default) = LDS-resident chains
   // (k_chain.hip) wherever they fit - BiFPN width 64 in every session dtype (fp32: streamed node weights) - and k_sep.hip chains elsewhere
-  const int chain_mode = getenv("HEP_CHAIN") ? atoi(getenv("HEP_CHAIN")) : 2;
+  const int chain_mode = P.kn.chain;
   for (int r = 0; r < A.fpn_cells; r++) {
     const std::string p = "bifpn." + std::to_string(r);
     const std::string tn = "c" + std::to_string(r) + ".";
@@ -1394,8 +1415,7 @@ int build_session(Session* s, const Pack& pack, std::string* err) {
                           {"p5_down", 2, L5, ".p5_down_channel", "p5_in"}, {"p4_down2", 1, L4, ".p4_down_channel_2", "p4_in2"},
                           {"p5_down2", 2, L5, ".p5_down_channel_2", "p5_in2"}, {"p5_to_p6", 2, L5, ".p5_to_p6", "p6_pre"}};
       int lat_out[6];
-      const char* ge = getenv("HEP_PWG");
-      if (!(ge && atoi(ge) == 0)) {
+      if (P.kn.pwg != 0) {
         std::vector<Planner::PwSpec> specs;
         for (const Lat& l : lat)
           specs.push_back({tn + l.nm, p + l.key + ".0.conv.weight", p + l.key + ".0.conv.bias", p + l.key + ".1", tn + l.out,
@@ -1489,13 +1509,15 @@ int build_session(Session* s, const Pack& pack, std::string* err) {
                             {4, "hand_net.initial_hand_coords", 63, 63, 0, 4, ACT_NONE}};
   // HEP_HEADS_FUSED: 1 = the towers depth-first in ONE launch (k_heads.hip; bf16 at BiFPN width 64), 0 = launch by launch
   bool heads_done = false;
-  if (getenv("HEP_HEADS_FUSED") ? atoi(getenv("HEP_HEADS_FUSED")) != 0 : false) {
+#ifdef HEP_ALT
+  if (P.kn.heads_fused != 0) {
     std::vector<std::string> nv(nets, nets + 5);
     std::vector<Planner::HeaderSpec> hv;
     for (const Hd& h : hds) hv.push_back({h.net, h.key, h.kin, h.kout, h.off, h.out, h.act});
     heads_done = P.add_heads_fused(nv, hv, feat, A.head_depth);
     if (!P.ok) return HEP_ERR_PACK;
   }
+#endif
   // one launch per tower layer (all five nets x five levels) + one for all headers (k_tower.hip)
   if (!heads_done) {
     int cur[5][5];
@@ -1592,8 +1614,10 @@ int build_session(Session* s, const Pack& pack, std::string* err) {
   if (tower_prepare() != 0) { *err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for tower_kernel"; return HEP_ERR_DEVICE; }
   if (filter_prepare() != 0) { *err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for filter_kernel"; return HEP_ERR_DEVICE; }
   if (sep_prepare() != 0) { *err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"; return HEP_ERR_DEVICE; }
+#ifdef HEP_ALT
   if (heads_prepare() != 0) { *err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for heads_kernel"; return HEP_ERR_DEVICE; }
   if (late_prepare() != 0) { *err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for late_kernel"; return HEP_ERR_DEVICE; }
+#endif
   HIPCHK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
   s->weights_bytes = P.wb.host.size();
   HIPCHK(hipMalloc((void**)&s->d_weights, s->weights_bytes));
@@ -1680,6 +1704,7 @@ int build_session(Session* s, const Pack& pack, std::string* err) {
         case F_CH_EXT_STORE: o.chain.ext[r.seg].store = ptr; break;
         case F_CH_NODE_OUT: o.cnodes[r.seg].out = ptr; break;
         case F_CH_WBLOB: o.chain.wblob = ptr; break;
+#ifdef HEP_ALT
         case F_SBF_WS: o.sbf.w_stem = (const float*)ptr; break;
         case F_SBF_BS: o.sbf.b_stem = (const float*)ptr; break;
         case F_SBF_WDW: o.sbf.wdw = (const float*)ptr; break;
@@ -1688,6 +1713,7 @@ int build_session(Session* s, const Pack& pack, std::string* err) {
         case F_SBF_OUT: o.sbf.out = ptr; break;
         case F_SBF_PART: o.sbf.hpart = (float*)ptr; break;
         case F_SBF_WR: o.sbf.se_wr = (const float*)ptr; break;
+#endif
         case F_XBF_IN: o.xbf.in = ptr; break;
         case F_XBF_HPART: o.xbf.hpart = (const float*)ptr; break;
         case F_XBF_SEBR: o.xbf.se_br = (const float*)ptr; break;
@@ -1699,6 +1725,7 @@ int build_session(Session* s, const Pack& pack, std::string* err) {
         case F_XBF_OUT: o.xbf.out = ptr; break;
         case F_XBF_PART: o.xbf.hpart_out = (float*)ptr; break;
         case F_XBF_WR: o.xbf.se_wr = (const float*)ptr; break;
+#ifdef HEP_ALT
         case F_HEADS_FEAT: o.heads.feat[r.seg] = ptr; break;
         case F_HEADS_BLOB: o.heads.blob = (const unsigned char*)ptr; break;
         case F_HEADS_OUT: o.heads.out[r.seg] = (float*)ptr; break;
@@ -1708,10 +1735,14 @@ int build_session(Session* s, const Pack& pack, std::string* err) {
         case F_LATE_HPART: o.late.hpart = (float*)ptr; break;
         case F_LATE_RES: o.late.blk[r.seg].res = ptr; break;
         case F_LATE_OUT: o.late.blk[r.seg].out = ptr; break;
+#endif
+        default: break;
       }
     }
     for (Op& o : ops) {
+#ifdef HEP_ALT
       if (o.kind == OP_LATE) o.late.counters = s->d_sync + (size_t)lane * sync_lane_words;
+#endif
       if (o.kind == OP_MBF && o.mbf.se_tail) o.mbf.tail_counter = s->d_sync + (size_t)lane * sync_lane_words + (size_t)s->lane_batch * 16 + (size_t)(o.mbf.se_tail - 1) * s->lane_batch * 32;
     }
     // segment tables to device
@@ -1728,7 +1759,8 @@ int build_session(Session* s, const Pack& pack, std::string* err) {
         o.sep.tile_seg = dt;
         o.sep.seg0 = o.segs[0];
       } else if (o.kind == OP_CHAIN) {
-        ChainNode* d; HIPCHK(hipMalloc((void**)&d, o.cnodes.size() * sizeof(ChainNode)));
+        // (whole 256-byte chunks: chain_kernel warms the scalar cache with one s_load_dword per 64-byte line of every chunk it touches)
+        ChainNode* d; HIPCHK(hipMalloc((void**)&d, (o.cnodes.size() * sizeof(ChainNode) + 255) & ~(size_t)255));
         HIPCHK(hipMemcpy(d, o.cnodes.data(), o.cnodes.size() * sizeof(ChainNode), hipMemcpyHostToDevice));
         o.chain.nodes = d;
       }

@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void stem_valu_kernel(StemArgs a) {
 
 // (read at every call - plan naming and launch - never cached: a session created after the environment changed gets the plan it asked for;
 //  stems wider than 64 channels have no MFMA instantiation and keep the VALU form)
-int stem_uses_mfma(int cout) { const char* force = getenv("HEP_STEM_MFMA"); return cout <= 64 && (force ? atoi(force) != 0 : cout > 32); }
+int stem_uses_mfma(int cout, int force) { return cout <= 64 && (force >= 0 ? force != 0 : cout > 32); }      // force: Knobs::stem_mfma (-1 = by width)
 
 void launch_stem(const StemArgs& a_, hipStream_t s) {
   StemArgs a = a_;
@@ -226,8 +226,7 @@ void launch_stem(const StemArgs& a_, hipStream_t s) {
     return;
   }
   const int TX = (a.Wo + 15) >> 4, total = a.B * a.Ho * TX;
-  const char* mpw_e = getenv("HEP_STEM_MPW"); const int mpw_env = mpw_e ? atoi(mpw_e) : 0;
-  a.mpw = mpw_env > 0 ? mpw_env : 2;                     // m-tiles per wave (measured 1 / 2 / 3 / 4 / 8: 21.2 / 18.5 / 21.4 / 19.7 / 26.1 us at phi 0)
+  a.mpw = 2;                     // m-tiles per wave (measured 1 / 2 / 3 / 4 / 8: 21.2 / 18.5 / 21.4 / 19.7 / 26.1 us at phi 0)
   a.tx_rcp = rcp_u32((uint32_t)TX); a.ho_rcp = rcp_u32((uint32_t)a.Ho);
   dim3 grid((unsigned)((total + 4 * a.mpw - 1) / (4 * a.mpw)));
   const int nt = (a.Cout + 15) >> 4;

@@ -671,10 +671,14 @@ __global__ __launch_bounds__(TS == 16 ? 1024 : 512) void mbf_kernel(MbfArgs a) {
       }
       dot += __shfl_xor(dot, 1, 64); dot += __shfl_xor(dot, 2, 64); dot += __shfl_xor(dot, 4, 64);
       if (part == 0 && j < a.sq) {
+#ifdef HEP_ALT
         if (a.se_tail) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dot), __builtin_amdgcn_make_buffer_rsrc(hrow, 0, 0x7fffffff, 0x00020000), j * 4, 0, 17);   // sc0 sc1: written through
-        else hrow[j] = dot;
+        else
+#endif
+        hrow[j] = dot;
       }
     }
+#ifdef HEP_ALT      // (alternative library only: HEP_SE_TAIL=1, a measured loss against se_finish_kernel - NOTEBOOK.md)
     // ---- tail: the image's LAST workgroup finishes the squeeze-excite (hidden vector, expand FC, sigmoid -> scale[b][Cexp]) ----
     // No workgroup waits for another one: a ticket per image, and whoever draws the last one has every row in memory (each
     // workgroup's stores are acknowledged - vmcnt(0) - and its lanes met at a barrier before its ticket is drawn) and reads the
@@ -694,6 +698,7 @@ __global__ __launch_bounds__(TS == 16 ? 1024 : 512) void mbf_kernel(MbfArgs a) {
       __syncthreads();
       if (*flag) se_finish_body<BF16, MBF_THREADS, true>(a.tail, b, 0, a.tail.C, threadIdx.x, reinterpret_cast<float*>(smem) + 32);
     }
+#endif
   }
 #ifdef HEP_MBF_TRACE
   MSTAMP(6);

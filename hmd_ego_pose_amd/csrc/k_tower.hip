@@ -766,13 +766,12 @@ extern "C" int hep_dbg_tower_trace(unsigned long long* host, int max_waves, int 
 
 void launch_tower(const SepArgs& a, hipStream_t s) {
   // images per workgroup: amortises the weight staging; keep >= ~1000 workgroups in the launch
-  const char* ipb_e = getenv("HEP_TOWER_IPB"); const int ipb_env = ipb_e ? atoi(ipb_e) : 0;
-  int ipb = ipb_env > 0 ? ipb_env : 1;
-  if (ipb_env <= 0) while (ipb < 4 && (int64_t)a.total_tiles * ((a.B + 2 * ipb - 1) / (2 * ipb)) >= 900) ipb *= 2;
+  int ipb = 1;
+  while (ipb < 4 && (int64_t)a.total_tiles * ((a.B + 2 * ipb - 1) / (2 * ipb)) >= 900) ipb *= 2;
   // cooperative form: the prologue (descriptor, 40 weight registers per lane, staging: 2.8 us traced) is paid per workgroup -
   // as many images as still leave ~1.5 workgroups per CU (phi 3 @ 512 b8: 8 -> 430 workgroups, 5.10k -> 5.14k frames/s; fp32 phi 0
   // b16: 4 -> 460; 8 -> 230 measured slower)
-  if (a.coop && ipb_env <= 0) { ipb = 8; while (ipb > 2 && (int64_t)a.total_tiles * ((a.B + ipb - 1) / ipb) < 400) ipb /= 2; }
+  if (a.coop) { ipb = 8; while (ipb > 2 && (int64_t)a.total_tiles * ((a.B + ipb - 1) / ipb) < 400) ipb /= 2; }
   ipb = std::min(ipb, a.B);
   const dim3 grid(a.total_tiles, (a.B + ipb - 1) / ipb);
   switch (a.C) {

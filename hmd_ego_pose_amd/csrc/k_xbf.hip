@@ -542,7 +542,6 @@ static void launch_xbf_n(const XbfArgs& a, dim3 grid, hipStream_t s) {
   else if (a.NT1 == 2) hipLaunchKernelGGL((xbf_kernel<BF16, KS, S, TOH, TOW, 2, 0, 0>), grid, dim3(XT), a.lds_bytes, s, a);
   else hipLaunchKernelGGL((xbf_kernel<BF16, KS, S, TOH, TOW, 3, 0, 0>), grid, dim3(XT), a.lds_bytes, s, a);
 }
-int xbf_generic_forced(void) { const char* e = getenv("HEP_XBF_GENERIC"); return e && atoi(e) != 0 ? 1 : 0; }
 template <bool BF16>
 static void launch_xbf_t(const XbfArgs& a, dim3 grid, hipStream_t s) {
   const bool generic = a.generic != 0;           // A/B switch, parity test of the generic path (decided when the plan is built)

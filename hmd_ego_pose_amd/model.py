@@ -144,6 +144,15 @@ class Session:
 
     def filter(self, boxes, classification, rotation, translation, hand, score_threshold=0.5, nms_threshold=0.5, max_detections=100):
         B, dev, M = boxes.shape[0], boxes.device, max_detections
+        # the C ABI takes bare pointers and indexes them as [B][N][K] with K from the weights: a tensor of another width would be read
+        # out of bounds on the device, so the shapes are checked here
+        N = self.num_anchors
+        for name, t, k in (("boxes", boxes, 4), ("classification", classification, self.num_classes), ("rotation", rotation, 3),
+                           ("translation", translation, 3), ("hand", hand, 63)):
+            if tuple(t.shape) != (B, N, k) or t.dtype != torch.float32 or t.device != dev:
+                raise ValueError(f"filter: {name} must be a float32 tensor of shape ({B}, {N}, {k}) on {dev}, got {t.dtype} {tuple(t.shape)} on {t.device}")
+        if not (B <= self.max_batch and 1 <= M <= 256):
+            raise ValueError(f"filter: batch {B} exceeds the session's {self.max_batch} or max_detections {M} is outside 1..256")
         f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
         i = lambda *s: torch.empty(s, dtype=torch.int32, device=dev)
         out = dict(boxes=f(B, M, 4), scores=f(B, M), labels=i(B, M), rotation=f(B, M, 3), translation=f(B, M, 3),

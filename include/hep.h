@@ -77,6 +77,9 @@ enum { HEP_OUT_FEAT1 = 0, HEP_OUT_FEAT5 = 4, HEP_OUT_REGRESSION = 5, HEP_OUT_CLA
        HEP_OUT_ROTATION = 7, HEP_OUT_TRANSLATION_RAW = 8, HEP_OUT_HAND = 9, HEP_NUM_OUTPUTS = 10 };
 
 int hep_abi_version(void);
+/* Which build of the library this is: "libhep gfx950" followed by the optional parts it was compiled with - " alt" (the rejected plan
+ * alternatives and their knobs: make alt), " fp8" (make fp8), " poison" (sanitizer build), " trace" (phase stamps).  Static storage. */
+const char* hep_build_info(void);
 const char* hep_last_error(void);
 
 /* Number of HIP devices visible; does not initialise the runtime beyond counting. */

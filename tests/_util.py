@@ -14,6 +14,9 @@ CASES = {  # tag -> (phi, size, batch, seed, input kind)
     # rounds of workgroups, two tiles per workgroup in the boundary kernels, the split-K tile of the project GEMMs)
     "phi0_s256_b16_seed0": (0, 256, 16, 0, "normal"),
     "phi3_s512_b8_seed0": (3, 512, 8, 0, "normal"),
+    # the regime of the reference's only published latency ("effnet_b0_512", FP32, batch 1: unity-sandbox/WebRTCNetCoreSandbox/Program.cs:24-33),
+    # what bench.py's latency_b1 block times
+    "phi0_s512_b1_seed0": (0, 512, 1, 0, "normal"),
 }
 CLASS_CASES = {  # tag -> (phi, size, batch, seed, input kind, num_classes): the classifier header with more than one class
     "phi0_s256_b2_seed0_k3": (0, 256, 2, 0, "normal", 3),

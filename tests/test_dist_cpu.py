@@ -94,6 +94,75 @@ def test_four_rank_gloo_uneven_and_empty_shards(G):
     assert sorted(res) == [(r, "ok") for r in range(4)], res
 
 
+def _worker8(rank, world, port, q, G):
+    """Configs 3 / 5 of BASELINE.json at their real shard arithmetic: G = 128 / 256 uint8 frames of 256x256x3 on eight ranks
+    (16 / 32 per rank), the flat weight broadcast of a phi-0-sized state_dict, and the gather of the post-filter rows."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cpu")
+    try:
+        torch.set_num_threads(1)
+        warm_up_p2p(dev)
+        # weights: a state_dict of the real phi 0 shapes (3.9 M floats in 1048 tensors), rank 0's values everywhere
+        from hmd_ego_pose_amd.weights import seeded_state_dict
+        sd0 = seeded_state_dict(0, 0)
+        mine_sd = sd0 if rank == 0 else {k: torch.zeros_like(v) for k, v in sd0.items()}
+        got_sd = broadcast_state_dict(mine_sd, dev)
+        assert all(torch.equal(got_sd[k], sd0[k]) for k in sd0 if torch.is_floating_point(sd0[k]))
+        # frames: row r of the global batch is filled with a value derived from r (cheap to build, exact to check)
+        S, M = 256, 100
+        if rank == 0:
+            frames = (torch.arange(G, dtype=torch.int32) * 7 % 251).to(torch.uint8).reshape(G, 1, 1, 1).expand(G, S, S, 3).contiguous()
+            frames[:, 0, 0, 0] = (torch.arange(G, dtype=torch.int32) % 256).to(torch.uint8)
+        else:
+            frames = None
+        lo, hi = shard_range(G, rank, world)
+        assert hi - lo == G // world                                  # 16 (config 3) / 32 (config 5) frames per rank
+        for _step in range(2):                                        # two steps: the grouped sends / receives are reusable
+            mine = scatter_frames(frames, G, (S, S, 3), dev, dtype=torch.uint8)
+            assert mine.shape == (hi - lo, S, S, 3) and mine.dtype == torch.uint8
+            idx = torch.arange(lo, hi, dtype=torch.int32)
+            assert torch.equal(mine[:, 5, 7, 1].to(torch.int32), idx * 7 % 251) and torch.equal(mine[:, 0, 0, 0].to(torch.int32), idx % 256)
+            # post-filter rows as hep_filter_device leaves them: [n, M, k] per key, int32 / float32
+            n = hi - lo
+            det = {"boxes": idx.float().reshape(n, 1, 1).expand(n, M, 4).contiguous(), "scores": idx.float().reshape(n, 1).expand(n, M).contiguous(),
+                   "labels": torch.zeros((n, M), dtype=torch.int32), "rotation": torch.zeros((n, M, 3)), "translation": torch.zeros((n, M, 3)),
+                   "hand": idx.float().reshape(n, 1, 1).expand(n, M, 63).contiguous(), "index": idx.reshape(n, 1).expand(n, M).contiguous(), "count": idx.clone()}
+            got = gather_detections(det, G)
+            if rank == 0:
+                want = torch.arange(G, dtype=torch.int32)
+                assert got["count"].shape == (G,) and torch.equal(got["count"], want)                 # global frame order on rank 0
+                assert got["boxes"].shape == (G, M, 4) and torch.equal(got["boxes"][:, 3, 2], want.float())
+                assert got["hand"].shape == (G, M, 63) and torch.equal(got["hand"][:, 99, 62], want.float())
+                assert got["index"].dtype == torch.int32 and torch.equal(got["index"][:, 0], want)
+            else:
+                assert got is None
+        assert max_over_ranks(float(rank + 1), dev) == float(world)
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, repr(e) + traceback.format_exc()[-600:]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("G", [128, 256])
+def test_eight_rank_gloo_config_shapes(G):
+    """BASELINE configs 3 (batch 128) and 5 (batch 256) on eight ranks: weight broadcast -> scatter of the uint8 frames (16 / 32 per
+    rank, 196 608 bytes each) -> gather of the detection rows, rows in global order on rank 0.  The first real 8-GPU run is the
+    driver's; this is the same code over gloo."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker8, args=(r, 8, port, q, G)) for r in range(8)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=300) for _ in ps]
+    for p in ps:
+        p.join(60)
+    assert sorted(res) == [(r, "ok") for r in range(8)], res
+
+
 def test_bench_refuses_more_gpus_than_visible_before_touching_one():
     """bench.py --gpus N without a torchrun environment: the parent checks the device count (no HIP initialisation) and
     exits non-zero instead of starting ranks that would hang in the rendezvous."""
