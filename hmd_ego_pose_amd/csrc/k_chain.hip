@@ -132,7 +132,7 @@ __global__ __launch_bounds__(CHAIN_THREADS) void chain_kernel(ChainArgs a) {
   T* halo = reinterpret_cast<T*>(smem + a.off_halo);
   T* atile = reinterpret_cast<T*>(smem + a.off_atile);
   const int C = a.C, CG = C >> 3, CH = C + PAD;
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, g = lane >> 4;
   int cgsh = 0; while ((1 << cgsh) < CG) cgsh++;
   const int cg = tid & ((1 << cgsh) - 1), prow = tid >> cgsh, pstride = CHAIN_THREADS >> cgsh;
 #ifdef HEP_MBF_TRACE

@@ -80,7 +80,7 @@ __global__ __launch_bounds__(TS == 16 ? 1024 : 512) void mbf_kernel(MbfArgs a) {
   unsigned long long stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   MSTAMP(0);
 #endif
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // (uniform: whatever is derived from it alone runs on the scalar unit)
   const int r = lane & 15, g = lane >> 4;
   // The prologue below runs in every wave of a latency-bound workgroup: its instruction count is kernel time
   // (measured with the phase-A stamps: 1250 instructions = 2.6 us before the last staging load was issued).  So every

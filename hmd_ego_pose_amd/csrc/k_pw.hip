@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void pw_group_kernel(PwgArgs a) {
   typedef typename V::elem T;
   typedef Frag<BF16> F;
   typedef typename F::raw raw_t;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 15, g = lane >> 4;
   int si = 0;                                    // segment of this strip (uniform; nseg <= 8)
 #pragma unroll
   for (int i = 1; i < PWG_MAX; i++) if (i < a.nseg && (int)blockIdx.x >= a.seg[i].blk_begin) si = i;

@@ -89,7 +89,7 @@ __global__ __launch_bounds__(NWV * 64) void pw_gemm_kernel(PwArgs a) {
   typedef typename V::elem T;
   typedef Frag<BF16> F;
   typedef typename F::raw raw_t;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // (uniform: tile origin and K slice on the scalar unit)
   const int r = lane & 15, g = lane >> 4;
   const int K = a.K, M = a.M;
   const T* A = reinterpret_cast<const T*>(a.A);

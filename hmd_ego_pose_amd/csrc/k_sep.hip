@@ -173,7 +173,7 @@ __global__ __launch_bounds__(SEP_THREADS_OF(MODE, BF16), MODE == 1 ? SEP_M1_WAVE
   // (index arithmetic below: channel groups and tile sides are split with shifts and masks, the halo
   //  side with a compile-time divisor per tile size - a run-time integer division costs ~30 VALU
   //  instructions and this kernel used to issue half a dozen of them per work item)
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 15, g = lane >> 4;
   const int rows_valid = min(TS, h - y0), cols_valid = min(TS, w - x0);
   const int mtv = TS == 16 ? rows_valid : (TS == 8 ? (rows_valid + 1) >> 1 : 1);   // 16-pixel m-tiles holding a valid pixel (TS 4: the whole tile)

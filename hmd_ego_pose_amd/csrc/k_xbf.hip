@@ -66,7 +66,7 @@ __global__ __launch_bounds__(XT, KS == 3 ? 4 : 2) void xbf_kernel(XbfArgs a) {  
   unsigned long long stamps[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
   XSTAMP(0);
-  int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;     // (re-derived per tile, see the tile loop)
+  int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, g = lane >> 4;     // (re-derived per tile, see the tile loop)
   const int K1 = K1C ? K1C : a.K1, N1 = a.N1, NT2 = NT2C ? NT2C : a.NT2, Cexp = NT2 * 16;
   const int W1P = K1 + PAD;
   T* a_s = reinterpret_cast<T*>(smem);                                    // [PIN][K1]  input tile (dead after P1)

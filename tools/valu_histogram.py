@@ -120,22 +120,33 @@ def analyse(insts, trip):
 def main():
     argv = sys.argv[1:]
     lib = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "hmd_ego_pose_amd", "libhep.so")
-    pat, trip, show_loops = DEFAULT, 8, False
+    pat, trip, show_loops, table, names_file = DEFAULT, 8, False, False, None
     while argv:
         a = argv.pop(0)
         if a == "--kernels": pat = argv.pop(0)
         elif a == "--trip": trip = int(argv.pop(0))
         elif a == "--loops": show_loops = True
+        elif a == "--table": table = True
+        elif a == "--names": names_file = argv.pop(0)
         else: lib = a
     rx = re.compile(pat)
+    exact = set(l.strip() for l in open(names_file)) if names_file else None
+    rows = []
     for co in code_objects(lib):
         fns = functions(co)
         names = subprocess.run(["c++filt"], input="\n".join(fns.keys()), capture_output=True, text=True).stdout.splitlines()
         for mangled, name in zip(fns.keys(), names):
             name = re.sub(r"^void ", "", name)
-            if not rx.search(name):
+            if exact is not None:
+                if re.sub(r"\(.*\)$", "", name) not in exact:
+                    continue
+            elif not rx.search(name):
                 continue
             insts = fns[mangled]
+            if table:      # one line per device function: static instruction counts by unit (before / after comparisons of a build)
+                cs = collections.Counter(classify(op).split(".")[0] for _, op, _ in insts)
+                rows.append((re.sub(r"\(.*\)$", "", name), len(insts), cs["valu"], cs["salu"], cs["vmem"], cs["lds"], cs["mfma"]))
+                continue
             loops, depth = analyse(insts, trip)
             stat, wgt = collections.Counter(), collections.Counter()
             ops_w = collections.Counter()
@@ -159,6 +170,15 @@ def main():
                     dd = sum(1 for h2, t2 in loops if h2 <= h and t <= t2)
                     print(f"   loop {h:#x}..{t:#x} depth {dd}: " + ", ".join(f"{k} {v}" for k, v in cs.most_common()))
             print()
+    if table:
+        _print_table(rows)
+
+
+def _print_table(rows):
+    print(f"{'device function':52s} {'instr':>6s} {'valu':>6s} {'salu':>6s} {'vmem':>5s} {'lds':>5s} {'mfma':>5s}")
+    for r in sorted(rows):
+        print(f"{r[0]:52s} {r[1]:6d} {r[2]:6d} {r[3]:6d} {r[4]:5d} {r[5]:5d} {r[6]:5d}")
+    print(f"{'total':52s} {sum(r[1] for r in rows):6d} {sum(r[2] for r in rows):6d} {sum(r[3] for r in rows):6d} {sum(r[4] for r in rows):5d} {sum(r[5] for r in rows):5d} {sum(r[6] for r in rows):5d}")
 
 
 if __name__ == "__main__":
