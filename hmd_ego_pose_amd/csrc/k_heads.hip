@@ -4,7 +4,7 @@
 // TranslationNet / HandNet; iter 0).  bf16 sessions, BiFPN width 64.
 //
 // Launch by launch (k_tower.hip) the towers are D launches that each read and write every map of every net (28 MB per layer at
-// phi 0 b16) plus one header launch: waves live 8.4 us of which 5.4 wait for their 6x6 halo from HBM (DESIGN.md section 2,
+// phi 0 b16) plus one header launch: waves live 8.4 us of which 5.4 wait for their 6x6 halo from HBM (NOTEBOOK.md section 2,
 // "Round 5").  Here a workgroup (16 waves) owns one 16x16 OUTPUT tile of one (net, level, image): the input region with a halo
 // of D + 1 pixels (24x24 at D = 3) is loaded ONCE into LDS and the layers run in place - a wave computes whole m-tiles (16 pixels:
 // depthwise taps from LDS straight into the MFMA operand layout, the 64x64 pointwise weights of the layer as eight fragments in

@@ -75,7 +75,7 @@ extern unsigned long long* g_pw_trace_host;     // device buffer (k_pw.hip); tra
 // the weights host-packed [n-tile][k-step][lane][8], the activations stored that way by the front kernel (k_mbf.hip, MbfArgs::out_frag:
 // [m-tile][k-step][lane][8]) - so every fragment load of a wave is ONE contiguous kilobyte instead of sixteen 64-byte row segments.
 // One CU pulls contiguous fragments at 85-94 GB/s with the loads these kernels keep in flight, row segments at ~41 (tools/wstream,
-// DESIGN.md section 2): the K loop of the late project convs was bound by exactly that.  Same fragments, same order: bit-identical.
+// NOTEBOOK.md section 2): the K loop of the late project convs was bound by exactly that.  Same fragments, same order: bit-identical.
 template <int PREC, int MT, int NT, int MODE, int ACT, int SEV, int NWV = 4, bool FRAG = false>
 __global__ __launch_bounds__(NWV * 64) void pw_gemm_kernel(PwArgs a) {
   static_assert(NWV == 4 || (MODE == 2 && (SEV == 0 || SEV == 3)), "eight waves: split-K with the scale copied from se_finish_kernel only");

@@ -4,7 +4,7 @@
     python tests/precision_bf16x3.py [phi size] > profiles/r04/bf16x3_emulation.txt
 
 The exact-fp32 MFMA (v_mfma_f32_16x16x4_f32) runs at 1/16 of the bf16 rate: 137 us of matrix pipe per batch-16 step at phi 0 even
-perfectly spread over the chip.  This script replaces every pointwise (1x1) product of the CPU oracle's folded
+perfectly spread over the chip (NOTEBOOK.md section 2).  This script replaces every pointwise (1x1) product of the CPU oracle's folded
 network by its split-bf16 emulation - activations and weights stay fp32, only the PRODUCT is formed from bf16 pieces with fp32
 accumulation - and reports the distance of the five heads and of the decoded pose (ADD, as bench.py's add_vs_ref) from the fp32 oracle:
   x3    x = xh + xl, w = wh + wl (bf16 each); xh.wh + xh.wl + xl.wh            three bf16 MFMAs per product

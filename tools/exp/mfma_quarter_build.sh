@@ -1,6 +1,6 @@
 #!/bin/bash
 # TIMING-ONLY build: every group of four exact-fp32 MFMAs (v_mfma_f32_16x16x4_f32) runs ONE of them - results are WRONG, loads / LDS
-# traffic / barriers are unchanged - to size what the matrix pipe costs an fp32 session (0.950 ms against
+# traffic / barriers are unchanged - to size what the matrix pipe costs an fp32 session (NOTEBOOK.md section 2, round 4: 0.950 ms against
 # 1.058 ms one batch, 28.2k against 24.7k frames/s with four in flight).  Works on a scratch copy of csrc/; the product library is untouched.
 #   tools/exp/mfma_quarter_build.sh && HEP_LIB=$PWD/hmd_ego_pose_amd/libhep_mfmaq.so python bench.py --precision fp32 --no-cpu-baseline --no-comm --no-fp32
 set -e
