@@ -263,7 +263,13 @@ __global__ __launch_bounds__(256, BF16 ? 4 : 2) void tower_kernel(const SepSeg* 
       }
     }
   };
-  raw_t* xa_s = reinterpret_cast<raw_t*>(smem + Cfg::OFF_XA) + wv * KS * 64 + lane;
+  raw_t* xa_w = reinterpret_cast<raw_t*>(smem + Cfg::OFF_XA) + wv * KS * 64;      // this wave's operand slots [k-step][lane]
+  raw_t* xa_s = xa_w + lane;
+  // quad form of the depthwise phase (bf16, width 64, halos in LDS): lane = (channel quad, patch row), see the image loop
+  constexpr bool DWQ = BF16 && Cfg::HALO && CW == 64;
+  const int dq_cq = lane & 15, dq_py = lane >> 4;
+  // operand slot of channels 4 cq .. 4 cq + 3 of pixel r = 4 py + px: k-step cq / 8, lane group (cq % 8) / 2, half cq & 1 of the 16-byte fragment
+  const int dq_slot = (((dq_cq >> 3) * 64 + ((dq_cq & 7) >> 1) * 16 + dq_py * 4) << 4) + (dq_cq & 1) * 8;
   if (nimg > 0) load_group(0, 0);
   TSTAMP_NOWAIT(2);                    // staging + first taps issued
   __syncthreads();                     // weights are in LDS; the first taps are in flight
@@ -295,6 +301,44 @@ __global__ __launch_bounds__(256, BF16 ? 4 : 2) void tower_kernel(const SepSeg* 
       if (bi + 1 < nimg) load_group(bi + 1, 0);
     }
   }
+  if constexpr (DWQ) {
+    // depthwise, quad form: lane = (channel quad cq, patch row py) computes the four pixels of its row for four channels.  The six halo
+    // columns of a tap row are read (8 bytes) and unpacked ONCE for the four pixels and a row's three weight vectors once: 18 + 9 LDS reads
+    // and 72 unpack instructions per image and lane instead of 18 + 36 reads (16 bytes each) and 144.  Taps in the order q = ky * 3 + kx
+    // into the same (c0, c2) / (c1, c3) accumulator pairs as Frag::fma_tap: bit-identical.
+    f32x2 ae[4], ao[4];
+#pragma unroll
+    for (int px = 0; px < 4; px++) { ae[px] = (f32x2){0.f, 0.f}; ao[px] = (f32x2){0.f, 0.f}; }
+    const T* hrow = halo + dq_py * HP + dq_cq * 4;
+#pragma unroll
+    for (int ky = 0; ky < 3; ky++) {
+      // the row's three weight vectors (one 16-byte LDS read each, shared by the four pixels), then the six halo columns one at a time:
+      // column hx feeds pixel px = hx - kx with tap kx, so every output still sees its taps in the order kx = 0, 1, 2
+      f32x2 we[3], wo[3];
+#pragma unroll
+      for (int kx = 0; kx < 3; kx++) {
+        const f32x4 wv4 = *reinterpret_cast<const f32x4*>(wdw_s + (ky * 3 + kx) * CW + dq_cq * 4);
+        we[kx] = (f32x2){wv4[0], wv4[1]}; wo[kx] = (f32x2){wv4[2], wv4[3]};
+      }
+#pragma unroll
+      for (int hx = 0; hx < 6; hx++) {
+        const u32x2 v = *reinterpret_cast<const u32x2*>(hrow + (hx * 6 + ky) * HP);
+        const f32x2 e = {__uint_as_float(v[0] << 16), __uint_as_float(v[1] << 16)};
+        const f32x2 o = {__uint_as_float(v[0] & 0xffff0000u), __uint_as_float(v[1] & 0xffff0000u)};
+#pragma unroll
+        for (int kx = 2; kx >= 0; kx--) {
+          const int px = hx - kx;
+          if (px >= 0 && px < 4) {
+            ae[px] = __builtin_elementwise_fma(e, we[kx], ae[px]);
+            ao[px] = __builtin_elementwise_fma(o, wo[kx], ao[px]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int px = 0; px < 4; px++)
+      *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned char*>(xa_w) + dq_slot + px * 16) = (u32x2){pack_bf16x2(ae[px][0], ao[px][0]), pack_bf16x2(ae[px][1], ao[px][1])};
+  } else
 #pragma unroll 1
   for (int gi = 0; gi < NG; gi++) {
 #pragma unroll
