@@ -523,93 +523,101 @@ __global__ __launch_bounds__(TS == 16 ? 1024 : 512) void mbf_kernel(MbfArgs a) {
   if constexpr (MP == 0) { MSTAMP(4); }
 
   // ---- phase C: depthwise taps from LDS -> global, SE sums ----
-  // A lane owns TWO horizontally adjacent output pixels: their kx windows overlap, so a row of
-  // S + KS input pixels is read (and unpacked) once for both and every weight vector read from LDS
-  // feeds two pixels.  The 256 (pixel pair, channel group) items are split over BOTH halves of the
-  // workgroup by tap row: waves 0-3 take the first (KS+1)/2 rows of taps, waves 4-7 the rest and hand
-  // their partial sums over through LDS (the dead input tile) - the phase is a chain of dependent LDS
-  // reads per tap row, so halving the rows per lane shortens it.
-  const int cgs = cc >> 3;
-  const int cgsh = cgs <= 1 ? 0 : 32 - __builtin_clz(cgs - 1), cgp = 1 << cgsh;
-  // (TS 16: 128 pixel pairs x 8 channel groups = one item per lane, all tap rows, no hand-over)
+  // A lane owns FOUR horizontally adjacent output pixels x FOUR channels (round 6; before: two pixels x eight channels): the 3 S + KS
+  // input columns of a tap row are read (8 bytes in bf16) and unpacked once for all four pixels and the row's KS weight vectors are read
+  // once - per tap row of a 5x5 stride-1 layer 8 + 5 LDS reads of 144 bytes and 32 unpack instructions instead of 6 + 10 reads of 256
+  // bytes and 48.  Every output still accumulates its taps in the order (ky, kx) ascending, and the squeeze-excite sums keep their
+  // tree (pixel pairs first, then pairs of pairs = this lane's four pixels, then the lanes): bit-identical to the two-pixel form.
+  // The (pixel quad, channel quad) items are split over BOTH halves of the workgroup by tap row on the 8x8 tiles: waves 0-3 take the
+  // first (KS+1)/2 rows of taps, waves 4-7 the rest and hand their partial sums over through LDS (the dead input tile) - the phase is a
+  // chain of dependent LDS reads per tap row, so halving the rows per lane shortens it.
+  const int cqs = cc >> 2;                                                 // channel quads of this chunk (cc is a multiple of 8)
+  const int cqsh = cqs <= 1 ? 0 : 32 - __builtin_clz(cqs - 1), cqp = 1 << cqsh;
+  // (TS 16: 64 pixel quads x 16 channel quads = one item per lane, all tap rows, no hand-over)
   constexpr bool SPLIT = TS == 8;
   constexpr int HALF = SPLIT ? MBF_THREADS / 2 : MBF_THREADS;
   const int half = SPLIT ? threadIdx.x / HALF : 0, tl = SPLIT ? threadIdx.x % HALF : threadIdx.x;
-  const int cg = tl & (cgp - 1), pp = tl >> cgsh;                          // pixel pair 0 .. TS*TS/2 - 1
+  const int cq = tl & (cqp - 1), qd = tl >> cqsh;                          // pixel quad 0 .. TS*TS/4 - 1
   f32x4* xch = reinterpret_cast<f32x4*>(smem);                             // [4][HALF] float4: partial sums of the second half (SPLIT)
-  float sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  const bool item = cg < cgs && pp < TS * TS / 2;
+  float sum[4] = {0, 0, 0, 0};
+  const bool item = cq < cqs && qd < TS * TS / 4;
   constexpr int KH = SPLIT ? (KS + 1) / 2 : KS;
-  float acc0[8], acc1[8];
-  constexpr int NX = S + KS;
-  const int py = pp / (TS / 2), px = (pp % (TS / 2)) * 2;
+  constexpr int NX = 3 * S + KS;                                           // input columns under four adjacent outputs
+  const int py = qd / (TS / 4), px = (qd % (TS / 4)) * 4;
+  float acc[4][4];                                                         // [pixel][channel]
   if (item) {
     {
-      const f32x4* bp = reinterpret_cast<const f32x4*>(bdw_s + cg * 8);
-      const f32x4 b0 = bp[0], b1 = bp[1];
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(bdw_s + cq * 4);
 #pragma unroll
-      for (int c = 0; c < 4; c++) { acc0[c] = half ? 0.f : b0[c]; acc0[4 + c] = half ? 0.f : b1[c]; acc1[c] = acc0[c]; acc1[4 + c] = acc0[4 + c]; }
+      for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) acc[j][c] = half ? 0.f : b0[c];
     }
 #pragma unroll 1      // a real loop: unrolled, the compiler hoists all KS*KS weight reads and spills
     for (int ky = half ? KH : 0; ky < (half ? KS : KH); ky++) {
-      float ev[NX][8];
+      f32x4 wr[KS];
 #pragma unroll
-      for (int j = 0; j < NX; j++) V::load(e_s, (int64_t)((py * S + ky) * PW + px * S + j) * EP + cg * 8, ev[j]);
+      for (int kx = 0; kx < KS; kx++) wr[kx] = *reinterpret_cast<const f32x4*>(wdw_s + (ky * KS + kx) * a.CC + cq * 4);
+      const int64_t erow = (int64_t)((py * S + ky) * PW + px * S) * EP + cq * 4;
 #pragma unroll
-      for (int kx = 0; kx < KS; kx++) {
-        const f32x4* wp = reinterpret_cast<const f32x4*>(wdw_s + (ky * KS + kx) * a.CC + cg * 8);
-        const f32x4 w0 = wp[0], w1 = wp[1];
+      for (int hx = 0; hx < NX; hx++) {
+        float ev[4];
+        V::load4(e_s, erow + (int64_t)hx * EP, ev);
+        // column hx is tap kx = hx - j S of output j: ascending hx = ascending kx for every output
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
-          acc0[c] = fmaf(ev[kx][c], w0[c], acc0[c]); acc0[4 + c] = fmaf(ev[kx][4 + c], w1[c], acc0[4 + c]);
-          acc1[c] = fmaf(ev[kx + S][c], w0[c], acc1[c]); acc1[4 + c] = fmaf(ev[kx + S][4 + c], w1[c], acc1[4 + c]);
+        for (int j = 3; j >= 0; j--) {
+          const int kx = hx - j * S;
+          if (kx >= 0 && kx < KS) {
+#pragma unroll
+            for (int c = 0; c < 4; c++) acc[j][c] = fmaf(ev[c], wr[kx][c], acc[j][c]);
+          }
         }
       }
     }
     if (SPLIT && half) {
-      xch[0 * HALF + tl] = (f32x4){acc0[0], acc0[1], acc0[2], acc0[3]}; xch[1 * HALF + tl] = (f32x4){acc0[4], acc0[5], acc0[6], acc0[7]};
-      xch[2 * HALF + tl] = (f32x4){acc1[0], acc1[1], acc1[2], acc1[3]}; xch[3 * HALF + tl] = (f32x4){acc1[4], acc1[5], acc1[6], acc1[7]};
+#pragma unroll
+      for (int j = 0; j < 4; j++) xch[j * HALF + tl] = (f32x4){acc[j][0], acc[j][1], acc[j][2], acc[j][3]};
     }
   }
   __syncthreads();
   if (item && !half) {
     if constexpr (SPLIT) {
-      const f32x4 p0 = xch[tl], p1 = xch[HALF + tl], p2 = xch[2 * HALF + tl], p3 = xch[3 * HALF + tl];
 #pragma unroll
-      for (int c = 0; c < 4; c++) { acc0[c] += p0[c]; acc0[4 + c] += p1[c]; acc1[c] += p2[c]; acc1[4 + c] += p3[c]; }
+      for (int j = 0; j < 4; j++) {
+        const f32x4 pj = xch[j * HALF + tl];
+#pragma unroll
+        for (int c = 0; c < 4; c++) acc[j][c] += pj[c];
+      }
     }
     const int oy = oy0 + py, ox = ox0 + px;
-    if (oy < a.Ho && ox < a.Wo) {
-      float v[8];
+    // (out_frag: the project GEMM's fragment order - row m = (image, pixel); a 16-byte unit holds KLANE channels from k:
+    //  unit ((m / 16) * ksteps + k / KSTEP) * 64 + (k % KSTEP) / KLANE * 16 + m % 16; bf16: a lane's four channels are half a unit)
+    auto ostore = [&](int ox_, const float* vv) {
+      const int m = (b * a.Ho + oy) * a.Wo + ox_, k = c0 + cq * 4;
+      if (!a.out_frag) { V::store4(a.out, (int64_t)m * a.Cexp + k, vv); return; }
+      constexpr int KST = BF16 ? 32 : 16, KLN = BF16 ? 8 : 4;
+      const int kst = (a.Cexp + KST - 1) / KST;
+      const int64_t unit = (int64_t)((m >> 4) * kst + k / KST) * 64 + ((k % KST) / KLN) * 16 + (m & 15);
+      V::store4(a.out, unit * KLN + (k & (KLN - 1)), vv);
+    };
+    if (oy < a.Ho) {
+      // channel sums in the order of the two-pixel form: (0 + v0) + v1 per pixel pair, then the two pairs
+      float sp[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-      for (int c = 0; c < 8; c++) v[c] = acc0[c];
-      swish_n<BF16, 8>(v);
+      for (int j = 0; j < 4; j++) {
+        // (the second pixel of a pair is only inside when the first one is: ox + j < Wo is the two-pixel form's nesting)
+        if (ox + j < a.Wo) {
+          float v[4];
 #pragma unroll
-      for (int c = 0; c < 8; c++) sum[c] += v[c];
-      // (out_frag: the project GEMM's fragment order - row m = (image, pixel); a 16-byte unit holds KLANE channels from k:
-      //  unit ((m / 16) * ksteps + k / KSTEP) * 64 + (k % KSTEP) / KLANE * 16 + m % 16; fp32: a lane's eight channels are two units)
-      auto ostore = [&](int ox_, const float* vv) {
-        const int m = (b * a.Ho + oy) * a.Wo + ox_, k = c0 + cg * 8;
-        if (!a.out_frag) { V::store(a.out, (int64_t)m * a.Cexp + k, vv); return; }
-        constexpr int KST = BF16 ? 32 : 16, KLN = BF16 ? 8 : 4;
-        const int kst = (a.Cexp + KST - 1) / KST;
+          for (int c = 0; c < 4; c++) v[c] = acc[j][c];
+          swish_n<BF16, 4>(v);
 #pragma unroll
-        for (int hlf = 0; hlf < 8 / KLN; hlf++) {
-          const int kk = k + hlf * KLN;
-          const int64_t unit = (int64_t)((m >> 4) * kst + kk / KST) * 64 + ((kk % KST) / KLN) * 16 + (m & 15);
-          if constexpr (BF16) V::store(a.out, unit * 8, vv);
-          else V::store4(a.out, unit * 4, vv + hlf * 4);
+          for (int c = 0; c < 4; c++) sp[j >> 1][c] += v[c];
+          ostore(ox + j, v);
         }
-      };
-      ostore(ox, v);
-      if (ox + 1 < a.Wo) {
-#pragma unroll
-        for (int c = 0; c < 8; c++) v[c] = acc1[c];
-        swish_n<BF16, 8>(v);
-#pragma unroll
-        for (int c = 0; c < 8; c++) sum[c] += v[c];
-        ostore(ox + 1, v);
       }
+#pragma unroll
+      for (int c = 0; c < 4; c++) sum[c] = sp[0][c] + sp[1][c];
     }
   }
   MSTAMP(5);
@@ -635,14 +643,11 @@ __global__ __launch_bounds__(TS == 16 ? 1024 : 512) void mbf_kernel(MbfArgs a) {
       wp0 = wp[0]; wp1 = wp[1];
     }
     if (wave < NWC) {
-      for (int off = cgp; off < 64; off <<= 1) {
+      for (int off = cqp; off < 64; off <<= 1) {                           // (the lane already holds a pair of pixel pairs: the first level of the old tree)
 #pragma unroll
-        for (int c = 0; c < 8; c++) sum[c] += __shfl_xor(sum[c], off, 64);
+        for (int c = 0; c < 4; c++) sum[c] += __shfl_xor(sum[c], off, 64);
       }
-      if (lane < cgs) {
-        f32x4* d = reinterpret_cast<f32x4*>(ssum + wave * a.CC + lane * 8);
-        d[0] = (f32x4){sum[0], sum[1], sum[2], sum[3]}; d[1] = (f32x4){sum[4], sum[5], sum[6], sum[7]};
-      }
+      if (lane < cqs) *reinterpret_cast<f32x4*>(ssum + wave * a.CC + lane * 4) = (f32x4){sum[0], sum[1], sum[2], sum[3]};
     }
     __syncthreads();
     float cs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
