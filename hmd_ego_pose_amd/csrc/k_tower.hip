@@ -265,11 +265,13 @@ __global__ __launch_bounds__(256, BF16 ? 4 : 2) void tower_kernel(const SepSeg* 
   };
   raw_t* xa_w = reinterpret_cast<raw_t*>(smem + Cfg::OFF_XA) + wv * KS * 64;      // this wave's operand slots [k-step][lane]
   raw_t* xa_s = xa_w + lane;
-  // quad form of the depthwise phase (bf16, width 64, halos in LDS): lane = (channel quad, patch row), see the image loop
-  constexpr bool DWQ = BF16 && Cfg::HALO && CW == 64;
+  // quad form of the depthwise phase (width 64, halos in LDS): lane = (channel quad, patch row), see the image loop
+  constexpr bool DWQ = Cfg::HALO && CW == 64;
   const int dq_cq = lane & 15, dq_py = lane >> 4;
-  // operand slot of channels 4 cq .. 4 cq + 3 of pixel r = 4 py + px: k-step cq / 8, lane group (cq % 8) / 2, half cq & 1 of the 16-byte fragment
-  const int dq_slot = (((dq_cq >> 3) * 64 + ((dq_cq & 7) >> 1) * 16 + dq_py * 4) << 4) + (dq_cq & 1) * 8;
+  // operand slot (byte offset) of channels 4 cq .. 4 cq + 3 of pixel r = 4 py + px.  bf16: k-step cq / 8, lane group (cq % 8) / 2, half cq & 1
+  // of the 16-byte fragment; fp32: k-step cq / 4, lane group cq % 4, the whole 16-byte fragment
+  const int dq_slot = BF16 ? (((dq_cq >> 3) * 64 + ((dq_cq & 7) >> 1) * 16 + dq_py * 4) << 4) + (dq_cq & 1) * 8
+                           : (((dq_cq >> 2) * 64 + (dq_cq & 3) * 16 + dq_py * 4) << 4);
   if (nimg > 0) load_group(0, 0);
   TSTAMP_NOWAIT(2);                    // staging + first taps issued
   __syncthreads();                     // weights are in LDS; the first taps are in flight
@@ -322,9 +324,15 @@ __global__ __launch_bounds__(256, BF16 ? 4 : 2) void tower_kernel(const SepSeg* 
       }
 #pragma unroll
       for (int hx = 0; hx < 6; hx++) {
-        const u32x2 v = *reinterpret_cast<const u32x2*>(hrow + (hx * 6 + ky) * HP);
-        const f32x2 e = {__uint_as_float(v[0] << 16), __uint_as_float(v[1] << 16)};
-        const f32x2 o = {__uint_as_float(v[0] & 0xffff0000u), __uint_as_float(v[1] & 0xffff0000u)};
+        f32x2 e, o;                                                  // bf16: channels (c0, c2) / (c1, c3) as Frag<true>; fp32: (c0, c1) / (c2, c3)
+        if constexpr (BF16) {
+          const u32x2 v = *reinterpret_cast<const u32x2*>(hrow + (hx * 6 + ky) * HP);
+          e = (f32x2){__uint_as_float(v[0] << 16), __uint_as_float(v[1] << 16)};
+          o = (f32x2){__uint_as_float(v[0] & 0xffff0000u), __uint_as_float(v[1] & 0xffff0000u)};
+        } else {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(hrow + (hx * 6 + ky) * HP);
+          e = (f32x2){v[0], v[1]}; o = (f32x2){v[2], v[3]};
+        }
 #pragma unroll
         for (int kx = 2; kx >= 0; kx--) {
           const int px = hx - kx;
@@ -336,8 +344,11 @@ __global__ __launch_bounds__(256, BF16 ? 4 : 2) void tower_kernel(const SepSeg* 
       }
     }
 #pragma unroll
-    for (int px = 0; px < 4; px++)
-      *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned char*>(xa_w) + dq_slot + px * 16) = (u32x2){pack_bf16x2(ae[px][0], ao[px][0]), pack_bf16x2(ae[px][1], ao[px][1])};
+    for (int px = 0; px < 4; px++) {
+      unsigned char* slot = reinterpret_cast<unsigned char*>(xa_w) + dq_slot + px * 16;
+      if constexpr (BF16) *reinterpret_cast<u32x2*>(slot) = (u32x2){pack_bf16x2(ae[px][0], ao[px][0]), pack_bf16x2(ae[px][1], ao[px][1])};
+      else *reinterpret_cast<f32x4*>(slot) = (f32x4){ae[px][0], ae[px][1], ao[px][0], ao[px][1]};
+    }
   } else
 #pragma unroll 1
   for (int gi = 0; gi < NG; gi++) {

@@ -1,7 +1,7 @@
 R="${GRAFT_REPO_ROOT:-$(pwd)}"
 cd /tmp && export TMPDIR=/tmp
 T="$R/gpurun_out/r4v2"; mkdir -p "$T"; rm -rf "$T/valu"
-timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_CVT SQ_INSTS_LDS --output-format csv -d $T/valu -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-comm --no-fp32 --sustain-seconds 0 $EXTRA_BENCH --inflight 1 > $T/bench_valu.log 2>&1
+timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_CVT SQ_INSTS_LDS --output-format csv -d $T/valu -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-comm --no-fp32 --no-latency --sustain-seconds 0 $EXTRA_BENCH --inflight 1 > $T/bench_valu.log 2>&1
 python3 - $T <<'PY'
 import csv, collections, glob, sys
 f = glob.glob(sys.argv[1] + "/valu/*/*_counter_collection.csv")[0]

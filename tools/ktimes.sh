@@ -3,7 +3,7 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 N=${1:-30}; [ $# -gt 0 ] && shift
 cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/kt
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python3 $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-comm --no-fp32 --sustain-seconds 0 --inflight 1 "$@" > /tmp/kt.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python3 $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-comm --no-fp32 --no-latency --sustain-seconds 0 --inflight 1 "$@" > /tmp/kt.log 2>&1
 python3 - "$N" <<'PY'
 import csv, glob, sys, json
 f = glob.glob("/tmp/kt/**/*kernel_stats.csv", recursive=True)[0]

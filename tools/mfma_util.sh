@@ -5,7 +5,7 @@
 R="${GRAFT_REPO_ROOT:-$(pwd)}"
 cd /tmp && export TMPDIR=/tmp
 T="$R/gpurun_out/$1"; mkdir -p "$T"; rm -rf "$T/mfma"
-timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $T/mfma -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-comm --no-fp32 --sustain-seconds 0 $EXTRA_BENCH --inflight 1 > $T/bench_mfma.log 2>&1
+timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $T/mfma -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-comm --no-fp32 --no-latency --sustain-seconds 0 $EXTRA_BENCH --inflight 1 > $T/bench_mfma.log 2>&1
 find $T/mfma -name "*agent_info.csv" -delete
 python3 - $T <<'PY'
 import csv, collections, glob, json, sys

@@ -28,12 +28,14 @@ for sfx in 1:"" p3:phi3_ f32:fp32_; do
   [ -d $d/pmc_fetch ] && pmc_json $d ${q}pmc_per_kernel.json
 done
 [ -f $T/bench_full.json ] && cp $T/bench_full.json ${P}_bench_full_line.json
-for n in phi3 b64 b32 fp8_b32 2rank_gloo; do [ -s $T/bench_$n.json ] && grep '^{' $T/bench_$n.json > ${P}_bench_${n}_line.json; done
+for n in phi3 b64 b32 fp8_b32 2rank_gloo 8rank_gloo; do [ -s $T/bench_$n.json ] && grep '^{' $T/bench_$n.json > ${P}_bench_${n}_line.json; done
 [ -f $T/conc.txt ] && grep -v amdgpu.ids $T/conc.txt > ${P}_concurrent_cost_per_launch.txt
 [ -f $T/conc_phi3.txt ] && grep -v amdgpu.ids $T/conc_phi3.txt > ${P}_phi3_concurrent_cost_per_launch.txt
 [ -f $T/conc_fp32.txt ] && grep -v amdgpu.ids $T/conc_fp32.txt > ${P}_fp32_concurrent_cost_per_launch.txt
 for n in fp32 bf16 phi3; do [ -f $T/plan_$n.txt ] && grep -v amdgpu.ids $T/plan_$n.txt > ${P}_plan_per_launch_$n.txt; done
 [ -f ${T}1/mfma_util.json ] && cp ${T}1/mfma_util.json ${P}_mfma_util.json
+[ -f ${T}1/valu_mix.json ] && cp ${T}1/valu_mix.json ${P}_valu_mix.json
+[ -f ${T}f32/valu_mix.json ] && cp ${T}f32/valu_mix.json ${P}_fp32_valu_mix.json
 [ -f $T/pytest.log ] && tail -3 $T/pytest.log > ${P}_pytest_gpu_tail.txt
 [ -f $T/pytest_fp8_tail.txt ] && cp $T/pytest_fp8_tail.txt ${P}_pytest_gpu_fp8_build_tail.txt
 [ -f $T/pytest_poison_tail.txt ] && cp $T/pytest_poison_tail.txt ${P}_pytest_gpu_poison_build_tail.txt

@@ -6,7 +6,7 @@
 R="${GRAFT_REPO_ROOT:-$(pwd)}"
 cd /tmp && export TMPDIR=/tmp
 T="$R/gpurun_out/$1"; mkdir -p "$T"; rm -rf "$T/valu"
-timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_CVT SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $T/valu -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-comm --no-fp32 --sustain-seconds 0 $EXTRA_BENCH --inflight 1 > $T/bench_valu.log 2>&1
+timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_CVT SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $T/valu -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-comm --no-fp32 --no-latency --sustain-seconds 0 $EXTRA_BENCH --inflight 1 > $T/bench_valu.log 2>&1
 find $T/valu -name "*agent_info.csv" -delete
 python3 - $T <<'PY'
 import csv, collections, glob, json, sys
