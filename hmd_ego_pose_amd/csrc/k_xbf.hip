@@ -347,59 +347,63 @@ __global__ __launch_bounds__(XT, KS == 3 ? 4 : 2) void xbf_kernel(XbfArgs a) {  
     if (ci == 0) XSTAMP(7);
     __syncthreads();
     if (ci == 0) XSTAMP(8);
-    // P3: depthwise.  Thread -> (pixel-pair group, 8-channel group); the channel group of a thread is fixed over its items
-    const int cgs = cc >> 3;
+    // P3: depthwise.  Thread -> (pixel-quad group, 4-channel group); the channel quad of a thread is fixed over its items.  An item is FOUR
+    // horizontally adjacent output pixels x four channels (round 6; before: two pixels x eight channels): the 3 S + KS input columns of a
+    // tap row are read and unpacked once for the four pixels and the row's KS weight vectors once.  Every output accumulates its taps in
+    // the order (ky, kx) ascending as before, and the squeeze-excite sums are kept per PIXEL PAIR in the two-pixel form's bookkeeping: the
+    // quad group qg carries the running sums of the old pixel-pair groups 2 qg and 2 qg + 1 (their items are the two halves of this
+    // thread's quads, in the same order) and P4 reads them from the rows those groups used to write - bit-identical whenever the number
+    // of pixel-pair groups XT / cgs is even (every BASELINE boundary; an odd count drops its last group: another fixed order).
+    const int cgs = cc >> 3, cqs = cc >> 2;
     cgs_of[ci] = cgs;
-    const float cgs_inv = __builtin_amdgcn_rcpf((float)cgs);
-    const int npg = udiv_f(XT, cgs, cgs_inv);                         // pixel-pair groups
-    const int pg = udiv_f(tid, cgs, cgs_inv), cg = tid - pg * cgs;
-    constexpr int NPP = TOH * TOW / 2, NX = S + KS;
-    if (pg < npg) {
-      float bias[8];
-      {
-        const f32x4* bp = reinterpret_cast<const f32x4*>(bdw_s + c0 + cg * 8);
-        const f32x4 q0 = bp[0], q1 = bp[1];
+    const float cgs_inv = __builtin_amdgcn_rcpf((float)cgs), cqs_inv = __builtin_amdgcn_rcpf((float)cqs);
+    const int npg = udiv_f(XT, cgs, cgs_inv) & ~1, nqg = npg >> 1;     // pixel-pair groups (even), pixel-quad groups
+    const int qg = udiv_f(tid, cqs, cqs_inv), cq = tid - qg * cqs;
+    constexpr int NQ = TOH * TOW / 4, NX = 3 * S + KS;
+    if (qg < nqg) {
+      const f32x4 bias = *reinterpret_cast<const f32x4*>(bdw_s + c0 + cq * 4);
+      T* out_b = reinterpret_cast<T*>(a.out) + (int64_t)b * a.Ho * a.Wo * Cexp + c0 + cq * 4;
+      for (int qd = qg; qd < NQ; qd += nqg) {
+        const int py = qd / (TOW / 4), px = (qd - py * (TOW / 4)) * 4;
+        float acc[4][4];
 #pragma unroll
-        for (int c = 0; c < 4; c++) { bias[c] = q0[c]; bias[4 + c] = q1[c]; }
-      }
-      T* out_b = reinterpret_cast<T*>(a.out) + (int64_t)b * a.Ho * a.Wo * Cexp + c0 + cg * 8;
-      for (int pp = pg; pp < NPP; pp += npg) {
-        const int py = pp / (TOW / 2), px = (pp - py * (TOW / 2)) * 2;
-        float acc0[8], acc1[8];
+        for (int j = 0; j < 4; j++)
 #pragma unroll
-        for (int c = 0; c < 8; c++) { acc0[c] = bias[c]; acc1[c] = bias[c]; }
+          for (int c = 0; c < 4; c++) acc[j][c] = bias[c];
 #pragma unroll 1
         for (int ky = 0; ky < KS; ky++) {
-          float ev[NX][8];
+          f32x4 wr[KS];
 #pragma unroll
-          for (int j = 0; j < NX; j++) V::load(e_s, ((py * S + ky) * PW + px * S + j) * EP + cg * 8, ev[j]);
+          for (int kx = 0; kx < KS; kx++) wr[kx] = *reinterpret_cast<const f32x4*>(wdw_s + (ky * KS + kx) * Cexp + c0 + cq * 4);
+          const int erow = ((py * S + ky) * PW + px * S) * EP + cq * 4;
 #pragma unroll
-          for (int kx = 0; kx < KS; kx++) {
-            const f32x4* wp = reinterpret_cast<const f32x4*>(wdw_s + (ky * KS + kx) * Cexp + c0 + cg * 8);
-            const f32x4 w0 = wp[0], w1 = wp[1];
+          for (int hx = 0; hx < NX; hx++) {
+            float ev[4];
+            V::load4(e_s, erow + hx * EP, ev);
+            // column hx is tap kx = hx - j S of output j: ascending hx = ascending kx for every output
 #pragma unroll
-            for (int c = 0; c < 4; c++) {
-              acc0[c] = fmaf(ev[kx][c], w0[c], acc0[c]); acc0[4 + c] = fmaf(ev[kx][4 + c], w1[c], acc0[4 + c]);
-              acc1[c] = fmaf(ev[kx + S][c], w0[c], acc1[c]); acc1[4 + c] = fmaf(ev[kx + S][4 + c], w1[c], acc1[4 + c]);
+            for (int j = 3; j >= 0; j--) {
+              const int kx = hx - j * S;
+              if (kx >= 0 && kx < KS) {
+#pragma unroll
+                for (int c = 0; c < 4; c++) acc[j][c] = fmaf(ev[c], wr[kx][c], acc[j][c]);
+              }
             }
           }
         }
         const int oy = oy0 + py, ox = ox0 + px;
-        if (oy < a.Ho && ox < a.Wo) {
-          float v[8];
+        if (oy < a.Ho) {
 #pragma unroll
-          for (int c = 0; c < 8; c++) v[c] = acc0[c];
-          swish_n<BF16, 8>(v);
+          for (int j = 0; j < 4; j++) {
+            if (ox + j < a.Wo) {
+              float v[4];
 #pragma unroll
-          for (int c = 0; c < 8; c++) sum[ci][c] += v[c];
-          V::store(out_b, (int64_t)((oy * a.Wo + ox) * Cexp), v);
-          if (ox + 1 < a.Wo) {
+              for (int c = 0; c < 4; c++) v[c] = acc[j][c];
+              swish_n<BF16, 4>(v);
 #pragma unroll
-            for (int c = 0; c < 8; c++) v[c] = acc1[c];
-            swish_n<BF16, 8>(v);
-#pragma unroll
-            for (int c = 0; c < 8; c++) sum[ci][c] += v[c];
-            V::store(out_b, (int64_t)((oy * a.Wo + ox + 1) * Cexp), v);
+              for (int c = 0; c < 4; c++) sum[ci][(j >> 1) * 4 + c] += v[c];      // [0..3]: the pair group 2 qg, [4..7]: 2 qg + 1
+              V::store4(out_b, (int64_t)((oy * a.Wo + ox + j) * Cexp), v);
+            }
           }
         }
       }
@@ -423,11 +427,19 @@ __global__ __launch_bounds__(XT, KS == 3 ? 4 : 2) void xbf_kernel(XbfArgs a) {  
   for (int ci = 0; ci < XCH; ci++) {
     if (ci >= a.nchunks) continue;
     const int cgs = cgs_of[ci], c0 = ci * a.chunk_tiles * 16, cc = cgs * 8;
-#pragma unroll
-    for (int c = 0; c < 8; c++) red9[tid][c] = sum[ci][c];
-    __syncthreads();
     const float cgs_inv = __builtin_amdgcn_rcpf((float)cgs);
-    const int npg = udiv_f(XT, cgs, cgs_inv);
+    const int npg = udiv_f(XT, cgs, cgs_inv) & ~1;                    // (even: see P3)
+    {
+      // row (pixel-pair group pg, channel octet cg) of the two-pixel form = this thread's halves: quad group qg = pg / 2, channel quad cq = 2 cg + {0, 1}
+      const int cqs = 2 * cgs, qg = udiv_f(tid, cqs, __builtin_amdgcn_rcpf((float)cqs)), cq = tid - qg * cqs;
+      if (qg < (npg >> 1)) {
+#pragma unroll
+        for (int hp = 0; hp < 2; hp++)
+#pragma unroll
+          for (int c = 0; c < 4; c++) red9[(2 * qg + hp) * cgs + (cq >> 1)][(cq & 1) * 4 + c] = sum[ci][hp * 4 + c];
+      }
+    }
+    __syncthreads();
     for (int c = tid; c < cc; c += XT) {
       const int cg = c >> 3, cl = c & 7;
       float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
