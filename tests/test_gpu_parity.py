@@ -526,6 +526,24 @@ def test_classifier_with_several_classes(api, tag, monkeypatch):
     assert set(np.unique(sel[2]).tolist()) - {-1} == set(range(classes))      # (every class is among the 100 rows: the labels are exercised)
 
 
+def test_filter_refuses_tensors_of_the_wrong_shape(api):
+    """The C ABI takes bare pointers and indexes them as [B][N][K] with K from the weights: the Python seam must refuse a classification
+    tensor of another width (a [B, N, 1] tensor handed to a three-class session once meant out-of-bounds device reads), and the other
+    four inputs likewise."""
+    sd = api["sd"](0, 0, num_classes=3)
+    s = api["Session"](sd, 0, 256, 2, "fp32")
+    N = s.num_anchors
+    z = lambda *sh: torch.zeros(sh, device="cuda")
+    good = dict(boxes=z(2, N, 4), classification=z(2, N, 3), rotation=z(2, N, 3), translation=z(2, N, 3), hand=z(2, N, 63))
+    assert int(s.filter(**good)["count"].sum()) == 0
+    for key, bad in (("classification", z(2, N, 1)), ("boxes", z(2, N, 5)), ("hand", z(2, N, 21)), ("rotation", z(2, N - 1, 3)), ("translation", z(2, N, 3).double())):
+        with pytest.raises(ValueError):
+            s.filter(**dict(good, **{key: bad}))
+    with pytest.raises(ValueError):
+        s.filter(**good, max_detections=257)
+    s.close()
+
+
 def test_filter_with_several_classes_fuzz(api):
     """The class-specific filter against the oracle on hostile inputs: tied scores across and inside classes, more candidates
     per class than LDS holds (global-memory sort), max_detections at the cap, a class with no candidate."""
