@@ -333,8 +333,10 @@ __global__ __launch_bounds__(256) void dw_kernel(DwArgs a) {
         const bool ok = rok && ix >= 0 && ix < a.W;
         float x[8];
         if constexpr (BF16) {
+          // the zero padding is selected on the four RAW words (zero bits unpack to 0.0f), not on the eight unpacked values
+          const raw_t xz = ok ? xr0[c0] : raw_t{};
 #pragma unroll
-          for (int q = 0; q < 4; q++) { x[2 * q] = ok ? __uint_as_float(xr0[c0][q] << 16) : 0.f; x[2 * q + 1] = ok ? __uint_as_float(xr0[c0][q] & 0xffff0000u) : 0.f; }
+          for (int q = 0; q < 4; q++) { x[2 * q] = __uint_as_float(xz[q] << 16); x[2 * q + 1] = __uint_as_float(xz[q] & 0xffff0000u); }
         } else {
 #pragma unroll
           for (int q = 0; q < 4; q++) { x[q] = ok ? xr0[c0][q] : 0.f; x[4 + q] = ok ? xr1[c0][q] : 0.f; }
@@ -366,7 +368,14 @@ __global__ __launch_bounds__(256) void dw_kernel(DwArgs a) {
       if (ox0 + p >= a.Wo) continue;
       float v[8];
 #pragma unroll
-      for (int c = 0; c < 8; c++) { v[c] = apply_act_t<BF16>(acc[p][c] + bias[c], a.act); sum[c] += v[c]; }
+      for (int c = 0; c < 8; c++) v[c] = acc[p][c] + bias[c];
+      if (a.act == ACT_SWISH) swish_n<BF16, 8>(v);                    // (uniform; the packed form: same operations, two values per issue slot)
+      else {
+#pragma unroll
+        for (int c = 0; c < 8; c++) v[c] = apply_act_t<BF16>(v[c], a.act);
+      }
+#pragma unroll
+      for (int c = 0; c < 8; c++) sum[c] += v[c];
       V::store(a.out, oimg + ((int64_t)oy * a.Wo + ox0 + p) * a.C + cg * 8, v);
     }
   }

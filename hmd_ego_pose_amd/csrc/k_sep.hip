@@ -343,7 +343,9 @@ __global__ __launch_bounds__(SEP_THREADS_OF(MODE, BF16), MODE == 1 ? SEP_M1_WAVE
       const f32x4 bias = *reinterpret_cast<const f32x4*>(bias_s + n);
       float v[4];
 #pragma unroll
-      for (int q = 0; q < 4; q++) v[q] = apply_act_t<BF16>(acc[q] + bias[q], sg.act);
+      for (int q = 0; q < 4; q++) v[q] = acc[q] + bias[q];
+      if (sg.act == ACT_SWISH) swish_n<BF16, 4>(v);                 // (uniform branches: BiFPN nodes have no activation behind the conv - the
+      else if (sg.act == ACT_SIGMOID) sigmoid_n<BF16, 4>(v);        //  branch-free select computed both transcendental forms for nothing)
       if (sg.out_f32) {
 #pragma unroll
         for (int q = 0; q < 4; q++) if (n + q < Nc) otile_f[(int64_t)m * Nc + n + q] = v[q];
