@@ -33,6 +33,10 @@ only at the timing barriers.  Rank 0 prints ONE JSON line.  It also carries
 The timed loop is fed by one submission thread per stream (joined before the closing barrier; a thread that raises fails the run):
 after a synchronize the first graph launch costs the host ~140 us, and with one Python thread the other streams wait behind it.
 `single_thread_value` is the same loop submitted from one thread.
+Before the --warmup steps every loop keeps the device busy with the same step for --preheat-ms (default 50, reported as `preheat_ms`;
+untimed set-up): an MI355X that has had no work for >= 10 ms runs its next ~20 ms of launches up to 8 % slower
+(tools/exp/window_ramp.py), and session set-up ends with such a gap.  The timed region itself is unchanged: exactly --steps steps
+between barrier + synchronize on both sides.
 """
 import argparse
 import ctypes
@@ -335,6 +339,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-layers", action="store_true", help="omit roofline.layers (one row per launch)")
     ap.add_argument("--no-latency", action="store_true", help="skip the latency_b1 block (phi 0 @ 512 fp32 batch 1 through the host C ABI)")
     ap.add_argument("--submit-threads", type=int, default=1, choices=[0, 1], help="1: one submission thread per stream feeds the timed loop (default); 0: the single-thread loop")
+    ap.add_argument("--preheat-ms", type=float, default=50.0, help="untimed set-up before the warm-up steps: the same step for this long, so that the device has left its idle power state (0: none)")
     ap.add_argument("--sustain-seconds", type=float, default=2.0, help="length of the `sustained` run (0: skip)")
     ap.add_argument("--comm-score-threshold", type=float, default=0.5)
     ap.add_argument("--comm-depth", type=int, default=4, help="batches in flight in the serving (comm) loop, at most --inflight")
@@ -526,6 +531,15 @@ def main():
             _capi.check(lib.hep_run_device(self.sess[d].handle, xs[d].data_ptr(), strides, B, None, None, st))
             _capi.check(lib.hep_decode_device(self.sess[d].handle, None, None, cam.data_ptr(), B, self.boxes[d].data_ptr(), self.trans[d].data_ptr(), st))
 
+        def preheat(self, seconds):
+            """Untimed set-up: keep the device busy with the same step for `seconds`.  After >= 10 ms without work an MI355X runs the next
+            ~20 ms of launches 8 % slower (tools/exp/window_ramp.py, profiles/r06/q_window_ramp_*.txt: consecutive 20-step windows right
+            after set-up 49.9k, 51.6k, 52.6k, 53.3k frames/s ...; 5 warm-up steps = 1.5 ms do not cover it)."""
+            t0 = time.perf_counter()
+            while seconds > 0 and time.perf_counter() - t0 < seconds:
+                self.run(4 * D)
+                torch.cuda.synchronize(dev)
+
         def timed(self, steps, depth=D, threads=True):
             torch.cuda.synchronize(dev); t0 = time.perf_counter()
             self.run(steps, depth, threads)
@@ -540,6 +554,8 @@ def main():
 
     main_loop = Loop(args.precision)
     N = main_loop.sess[0].num_anchors
+    hd.barrier()
+    main_loop.preheat(args.preheat_ms / 1e3)      # device out of its idle power state (reported as `preheat_ms`), THEN the --warmup steps
     main_loop.run(args.warmup)
     hd.barrier(); torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
@@ -549,6 +565,7 @@ def main():
     # the same window submitted from ONE thread (what `value` was until round 5): a side figure
     single_elapsed = None
     if main_loop.pool is not None:
+        main_loop.preheat(args.preheat_ms / 1e3)
         main_loop.timed(args.warmup, threads=False)
         single_elapsed = hd.max_over_ranks(main_loop.timed(args.steps, threads=False), dev)
     assert all(torch.isfinite(t).all() for t in main_loop.boxes) and all(torch.isfinite(t).all() for t in main_loop.trans)
@@ -641,7 +658,7 @@ def main():
         ms = elapsed / args.steps * 1e3
         out = {
             "metric": METRIC if (B, S, phi) == (16, 256, 0) else f"frames/sec at {S}x{S} bs{B} EfficientPose-phi{phi}; ADD(-S) vs ref", "value": round(B * world * args.steps / elapsed, 2), "unit": "frames/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "preheat_ms": args.preheat_ms, "ms_per_step": round(ms, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic",
             "config": {"workload": f"EfficientPose phi={phi} {S}x{S} {args.precision} batch={B} per GPU: forward (stem, MBConv, BiFPN, 5 heads) "
@@ -675,8 +692,9 @@ def main():
                 # the precision that meets the 0.1 mm ADD bound on the seeded weights (add_vs_ref below): same loops, fp32 sessions
                 main_loop.close()
                 f32 = Loop("fp32")
+                f32.preheat(args.preheat_ms / 1e3)
                 f32.timed(args.warmup)
-                # (at least 200 steps: a timed region pays ~0.35 ms of fill and drain whatever its length - 5 % of 20 steps - and this block,
+                # (at least 200 steps: a 20-step window is 11 ms - fill, drain and clock noise are 2-3 % of it - and this block,
                 #  unlike `value`, is not bound to exactly --steps)
                 kf = max(args.steps, 200)
                 ef = f32.timed(kf) * args.steps / kf          # (scaled to --steps: the fields below keep their meaning)
