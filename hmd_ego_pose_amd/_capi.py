@@ -41,6 +41,7 @@ SYMBOLS = {
     "hep_decode_device": (c_int, [_P, _FP, _FP, _FP, c_int, _FP, _FP, c_void_p]),
     "hep_preprocess_u8_device": (c_int, [_P, c_void_p, c_int, c_int, c_int, _FP, c_void_p]),
     "hep_preprocess_i420_device": (c_int, [_P, c_void_p, c_int, c_int, c_int, c_int, c_int, _FP, c_void_p]),
+    "hep_set_class_specific_filter": (c_int, [_P, c_int]),
     "hep_filter": (c_int, [_P, _FP, _FP, _FP, _FP, _FP, c_int, c_float, c_float, c_int] + [_FP] * 8),
     "hep_filter_device": (c_int, [_P, _FP, _FP, _FP, _FP, _FP, c_int, c_float, c_float, c_int] + [_FP] * 8 + [c_void_p]),
     "hep_pose_errors": (c_int, [c_int, _FP, c_int, _FP, _FP, _FP, _FP, c_int, c_int, _FP, _FP]),

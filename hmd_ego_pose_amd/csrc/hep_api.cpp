@@ -541,13 +541,20 @@ static int filter_locked(Session& s, const float* boxes, const float* classifica
   a.hand = hand ? hand : s.d_out[4];
   a.B = batch; a.N = s.num_anchors; a.max_det = max_detections; a.score_thr = score_threshold; a.nms_thr = nms_threshold;
   a.keys = s.d_keys; a.npow2 = s.npow2;
-  a.K = s.num_classes; a.part_idx = s.d_part; a.part_cnt = s.d_part ? s.d_part + (size_t)s.max_batch * s.num_classes * FILTER_MAX_DET : nullptr;
+  a.K = s.num_classes; a.any_class = s.class_specific_filter ? 0 : 1; a.part_idx = s.d_part; a.part_cnt = s.d_part ? s.d_part + (size_t)s.max_batch * s.num_classes * FILTER_MAX_DET : nullptr;
   a.det_boxes = det_boxes; a.det_scores = det_scores; a.det_labels = det_labels; a.det_rotation = det_rotation;
   a.det_translation = det_translation; a.det_hand = det_hand; a.det_index = det_index; a.det_count = det_count;
   launch_filter(a, st);
   HIPRET(hipGetLastError());
   return 0;
 }
+
+int hep_set_class_specific_filter(hep_handle* h, int on) try {
+  if (!h) return fail(HEP_ERR_INVALID, "bad argument");
+  std::lock_guard<std::mutex> lk(h->s.mu);
+  h->s.class_specific_filter = on ? 1 : 0;
+  return 0;
+} HEP_CATCH_INT
 
 int hep_filter_device(hep_handle* h, const float* boxes, const float* classification, const float* rotation,
                       const float* translation, const float* hand, int batch, float score_threshold, float nms_threshold,

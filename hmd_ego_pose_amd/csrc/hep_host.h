@@ -71,6 +71,7 @@ struct Session {
   std::vector<std::vector<Op>> lane_ops; std::vector<hipStream_t> lane_streams; std::vector<hipEvent_t> lane_events;
   hipEvent_t fork_event = nullptr;
   int levels[5]; int level_off[5]; int num_anchors;
+  int class_specific_filter = 1;    // hep_set_class_specific_filter: 0 = one filter pass over every anchor's best class (layers.py:359-362)
   int num_classes = 1;              // columns of the classification output: the classifier header holds 9 * num_classes channels (efficientdet/model.py:393)
   int out_k(int i) const { static const int k[5] = {4, 1, 3, 3, 63}; return i == 1 ? num_classes : k[i]; }   // values per anchor of head output i
   std::vector<TensorDesc> tensors;

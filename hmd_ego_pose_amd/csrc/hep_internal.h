@@ -299,6 +299,7 @@ struct FilterArgs {
   const float* boxes; const float* scores; const float* rotation; const float* translation; const float* hand;
   int B, N, max_det; float score_thr, nms_thr;
   int K;               // classes: scores are [B][N][K]; one workgroup per (image, class)
+  int any_class;       // class_specific_filter=False (layers.py:359-362): one pass per image over every anchor's best class
   int32_t* part_idx;   // K > 1: [B][K][max_det] anchors kept per class, in NMS order; part_cnt [B][K] (filter_merge_kernel reads them)
   int32_t* part_cnt;
   uint64_t* keys;      // workspace [B * K][Npow2] sort keys

@@ -49,9 +49,11 @@ void launch_decode(const DecodeArgs& a, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// filter_detections (reference hmdegopose/layers.py:264-400), class_specific_filter=True (the only mode the reference
+// filter_detections (reference hmdegopose/layers.py:264-400).  class_specific_filter=True (the mode the reference
 // constructs, train.py:78-81): one workgroup (1024 lanes) per (image, class); with more than one class
-// filter_merge_kernel then takes the top max_detections of all classes' survivors.
+// filter_merge_kernel then takes the top max_detections of all classes' survivors.  class_specific_filter=False
+// (layers.py:359-362, FilterArgs::any_class): one workgroup per image over every anchor's best class (max / FIRST argmax over
+// the class columns); its NMS order already is the top_k order, so the rows are emitted directly with label = that argmax.
 //   1. key[n] = score>thr ? (score_bits << 32 | ~n) : 0      (positive floats order as integers)
 //   2. bitonic sort, descending: score desc, equal scores -> lower anchor index first
 //   3. greedy NMS over the sorted candidates in chunks of 1024: a candidate dies when its IoU
@@ -70,6 +72,14 @@ __device__ __forceinline__ float iou_box(const f32x4 p, const f32x4 q) {
   const float ih = fmaxf(fminf(ay1, by1) - fmaxf(ay0, by0), 0.f);
   const float inter = iw * ih;
   return inter / ((aa + ab) - inter);
+}
+
+// score and class of an anchor's best class: max over the K columns, the first column on ties (keras.backend.max / argmax)
+__device__ __forceinline__ float best_class(const float* row, int K, int* label) {
+  float m = row[0]; int l = 0;
+  for (int c = 1; c < K; c++) { const float v = row[c]; if (v > m) { m = v; l = c; } }
+  *label = l;
+  return m;
 }
 
 #define FILTER_THREADS 1024
@@ -130,7 +140,9 @@ __global__ __launch_bounds__(FILTER_THREADS) void filter_kernel(FilterArgs a) {
   __shared__ int kept_idx[FILTER_MAX_DET];
   __shared__ int s_nkept, s_count;
   const int b = blockIdx.x, cls = blockIdx.y, K = a.K, tid = threadIdx.x, lane = tid & 63;
+  const bool anyc = a.any_class != 0 && K > 1;                              // (uniform; grid.y is 1 then)
   const float* scores = a.scores + (int64_t)b * a.N * K + cls;              // [N][K]: this class's column
+  auto score_of = [&](int n) { int l; return anyc ? best_class(scores + (int64_t)n * K, K, &l) : scores[(int64_t)n * K]; };
   const f32x4* boxes = reinterpret_cast<const f32x4*>(a.boxes) + (int64_t)b * a.N;
   const int cap = min(a.npow2, FILTER_LDS_KEYS);
 
@@ -139,7 +151,7 @@ __global__ __launch_bounds__(FILTER_THREADS) void filter_kernel(FilterArgs a) {
   // (1) compaction: one LDS atomic per wave and pass
   for (int n0 = 0; n0 < a.N; n0 += FILTER_THREADS) {
     const int n = n0 + tid;
-    const float sc = n < a.N ? scores[(int64_t)n * K] : 0.f;
+    const float sc = n < a.N ? score_of(n) : 0.f;
     const bool cand = n < a.N && sc > a.score_thr;
     const unsigned long long m = __ballot(cand);
     if (m) {
@@ -165,7 +177,7 @@ __global__ __launch_bounds__(FILTER_THREADS) void filter_kernel(FilterArgs a) {
     for (int n = tid; n < a.npow2; n += FILTER_THREADS) {
       uint64_t k = 0;
       if (n < a.N) {
-        const float sc = scores[(int64_t)n * K];
+        const float sc = score_of(n);
         if (sc > a.score_thr) k = ((uint64_t)__float_as_uint(sc) << 32) | (uint32_t)(~(uint32_t)n);
       }
       keys[n] = k;
@@ -205,6 +217,10 @@ __global__ __launch_bounds__(FILTER_THREADS) void filter_kernel(FilterArgs a) {
   }
   __syncthreads();
   const int nk = s_nkept;
+  if (anyc) {        // best class per anchor: NMS order = descending score, ties by anchor = the top_k order of layers.py:365-367
+    filter_emit(a, b, nk, tid, [&](int i) { return kept_idx[i]; }, [&](int i) { int l; best_class(scores + (int64_t)kept_idx[i] * K, K, &l); return l; });
+    return;
+  }
   if (K > 1) {       // one of several classes: the survivors go to filter_merge_kernel (top-k over all classes)
     for (int i = tid; i < nk; i += FILTER_THREADS) a.part_idx[(int64_t)(b * K + cls) * a.max_det + i] = kept_idx[i];
     if (tid == 0) a.part_cnt[b * K + cls] = nk;
@@ -248,8 +264,9 @@ int filter_prepare(void) {
 }
 void launch_filter(const FilterArgs& a, hipStream_t s) {
   const size_t lds = (size_t)std::min(a.npow2, FILTER_LDS_KEYS) * 8;
-  hipLaunchKernelGGL(filter_kernel, dim3(a.B, a.K), dim3(FILTER_THREADS), lds, s, a);
-  if (a.K > 1) {
+  const bool anyc = a.any_class != 0 && a.K > 1;
+  hipLaunchKernelGGL(filter_kernel, dim3(a.B, anyc ? 1 : a.K), dim3(FILTER_THREADS), lds, s, a);
+  if (a.K > 1 && !anyc) {
     int np2 = 64;
     while (np2 < a.K * a.max_det) np2 <<= 1;
     hipLaunchKernelGGL(filter_merge_kernel, dim3(a.B), dim3(FILTER_THREADS), (size_t)np2 * 8, s, a);

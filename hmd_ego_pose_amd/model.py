@@ -50,6 +50,7 @@ class Session:
         _capi.check(_capi.lib().hep_create_from_memory(blob, len(blob), phi, size, max_batch, _PRECISIONS[precision],
                                                        self.device.index or 0, flags, ctypes.byref(h)))
         self.handle = h.value
+        self._class_specific = True      # the handle's filter mode (hep_set_class_specific_filter)
         self.num_anchors = _capi.lib().hep_num_anchors(self.handle)
         self.num_classes = _capi.lib().hep_num_classes(self.handle)      # read from the classifier header of the weights
         self.out_width = tuple(self.num_classes if i == 1 else k for i, k in enumerate(OUT_WIDTH))
@@ -142,7 +143,10 @@ class Session:
                                                   cam.data_ptr(), B, boxes.data_ptr(), trans.data_ptr(), stream))
         return boxes, trans
 
-    def filter(self, boxes, classification, rotation, translation, hand, score_threshold=0.5, nms_threshold=0.5, max_detections=100):
+    def filter(self, boxes, classification, rotation, translation, hand, score_threshold=0.5, nms_threshold=0.5, max_detections=100,
+               class_specific_filter=True):
+        """filter_detections (hmdegopose/layers.py:264-400) for every image of the batch; class_specific_filter=False takes every
+        anchor's best class and filters those in one pass (layers.py:359-362)."""
         B, dev, M = boxes.shape[0], boxes.device, max_detections
         # the C ABI takes bare pointers and indexes them as [B][N][K] with K from the weights: a tensor of another width would be read
         # out of bounds on the device, so the shapes are checked here (ADVICE r05)
@@ -159,6 +163,9 @@ class Session:
                    hand=f(B, M, 63), index=i(B, M), count=i(B))
         stream = torch.cuda.current_stream(dev).cuda_stream
         args = [t.contiguous() for t in (boxes, classification, rotation, translation, hand)]
+        if bool(class_specific_filter) != self._class_specific:
+            _capi.check(_capi.lib().hep_set_class_specific_filter(self.handle, int(bool(class_specific_filter))))
+            self._class_specific = bool(class_specific_filter)
         _capi.check(_capi.lib().hep_filter_device(self.handle, *[t.data_ptr() for t in args], B, float(score_threshold),
                                                   float(nms_threshold), M, *[out[k].data_ptr() for k in
                                                                              ("boxes", "scores", "labels", "rotation", "translation", "hand", "index", "count")],
@@ -269,14 +276,14 @@ _FILTER_KEYS = ("boxes", "scores", "labels", "rotation", "translation", "hand", 
 
 @torch.library.custom_op("hep::filter", mutates_args=())
 def hep_filter(boxes: torch.Tensor, classification: torch.Tensor, rotation: torch.Tensor, translation: torch.Tensor, hand: torch.Tensor,
-               score_threshold: float, nms_threshold: float, max_detections: int, handle: int) -> List[torch.Tensor]:
+               score_threshold: float, nms_threshold: float, max_detections: int, handle: int, class_specific_filter: bool = True) -> List[torch.Tensor]:
     """filter_detections (hmdegopose/layers.py:264-400): boxes, scores, labels, rotation, translation, hand, index, count."""
-    d = _session(handle).filter(boxes, classification, rotation, translation, hand, score_threshold, nms_threshold, max_detections)
+    d = _session(handle).filter(boxes, classification, rotation, translation, hand, score_threshold, nms_threshold, max_detections, class_specific_filter)
     return [d[k] for k in _FILTER_KEYS]
 
 
 @hep_filter.register_fake
-def _(boxes, classification, rotation, translation, hand, score_threshold, nms_threshold, max_detections, handle):
+def _(boxes, classification, rotation, translation, hand, score_threshold, nms_threshold, max_detections, handle, class_specific_filter=True):
     B, M = boxes.shape[0], max_detections
     f = lambda *s: boxes.new_empty(s)
     i = lambda *s: boxes.new_empty(s, dtype=torch.int32)
@@ -409,12 +416,12 @@ class TrainModelWithLoss(nn.Module):
         self.model = model
 
     @torch.no_grad()
-    def detect(self, imgs, camera_params, score_threshold=0.5, nms_threshold=0.5, max_detections=100):
+    def detect(self, imgs, camera_params, score_threshold=0.5, nms_threshold=0.5, max_detections=100, class_specific_filter=True):
         _, regression, classification, rotation, translation_raw, hand = self.model(imgs)
         s = self.model.session(int(imgs.shape[-1]), int(imgs.shape[0]), imgs.device)
         boxes, translation = torch.ops.hep.decode(regression, translation_raw, camera_params.to(imgs.device), s.handle)
         out = torch.ops.hep.filter(boxes, classification, rotation, translation, hand, float(score_threshold), float(nms_threshold),
-                                   int(max_detections), s.handle)
+                                   int(max_detections), s.handle, bool(class_specific_filter))
         return dict(zip(_FILTER_KEYS, out))
 
     @torch.no_grad()

@@ -149,6 +149,11 @@ int hep_decode_device(hep_handle* h, const float* regression, const float* trans
  * det_boxes [batch,M,4], det_scores [batch,M], det_labels [batch,M] (int32), det_rotation [batch,M,3],
  * det_translation [batch,M,3], det_hand [batch,M,63], det_index [batch,M] (int32 anchor index),
  * det_count [batch] (int32).  Any output except det_count may be NULL. */
+/* class_specific_filter of FilterDetections (layers.py:403-433, filter_detections :347-362).  on != 0 (the default, and the only mode
+ * the reference constructs): as described above.  on == 0: ONE pass per image over every anchor's best class - score = max over the
+ * class columns, det_labels = the first argmax - thresholded, suppressed and cut to max_detections like a single class.  With one
+ * class both modes are the same pass.  Applies to the following hep_filter / hep_filter_device calls on this handle. */
+int hep_set_class_specific_filter(hep_handle* h, int on);
 int hep_filter(hep_handle* h, const float* boxes, const float* classification, const float* rotation,
                const float* translation, const float* hand, int batch, float score_threshold,
                float nms_threshold, int max_detections, float* det_boxes, float* det_scores,

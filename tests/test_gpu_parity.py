@@ -559,12 +559,53 @@ def test_filter_with_several_classes_fuzz(api):
         cls[1, :, classes - 1] = 0.0                                                     # the last class of image 1 passes nothing
         rot = rng.standard_normal((2, N, 3)).astype(np.float32); hand = rng.standard_normal((2, N, 63)).astype(np.float32)
         t = lambda a: torch.from_numpy(a).cuda()
-        det = s.filter(t(boxes), t(cls), t(rot), t(-rot), t(hand), score_threshold=thr, nms_threshold=0.5, max_detections=M)
-        for i in range(2):
-            o = D.filter_detections(boxes[i], cls[i], rot[i], -rot[i], hand[i], score_threshold=thr, max_detections=M, nms_threshold=0.5)
-            for key, want in zip(("boxes", "scores", "labels", "rotation", "translation", "hand", "index"), o):
-                assert np.array_equal(det[key][i].cpu().numpy(), want), (classes, i, key)
+        # both modes of the reference's switch (layers.py:347-362), and back: the mode is a property of the handle
+        for specific in (True, False, True):
+            det = s.filter(t(boxes), t(cls), t(rot), t(-rot), t(hand), score_threshold=thr, nms_threshold=0.5, max_detections=M, class_specific_filter=specific)
+            for i in range(2):
+                o = D.filter_detections(boxes[i], cls[i], rot[i], -rot[i], hand[i], score_threshold=thr, max_detections=M, nms_threshold=0.5,
+                                        class_specific_filter=specific)
+                for key, want in zip(("boxes", "scores", "labels", "rotation", "translation", "hand", "index"), o):
+                    assert np.array_equal(det[key][i].cpu().numpy(), want), (classes, specific, i, key)
+                assert int(det["count"][i]) == int((o[6] >= 0).sum())
         s.close()
+
+
+def test_best_class_filter_through_the_host_abi_and_the_module(api):
+    """class_specific_filter=False (layers.py:359-362) through hep_set_class_specific_filter + hep_filter on host arrays, and through
+    TrainModelWithLoss.detect; with one class the two modes are the same pass."""
+    import ctypes
+    from hmd_ego_pose_amd import _capi
+    D = api["D"]
+    lib = _capi.lib()
+    classes, size, M = 3, 256, 50
+    s = api["Session"](api["sd"](0, 0, num_classes=classes), 0, size, 1, "fp32")
+    N = s.num_anchors
+    rng = np.random.Generator(np.random.PCG64(77))
+    cxy = rng.uniform(20, size - 20, (1, N, 2)); wh = rng.uniform(4, 60, (1, N, 2))
+    boxes = np.concatenate([cxy - wh / 2, cxy + wh / 2], axis=2).astype(np.float32)
+    cls = (rng.integers(0, 256, (1, N, classes)) / 256.0).astype(np.float32)
+    rot = rng.standard_normal((1, N, 3)).astype(np.float32); hand = rng.standard_normal((1, N, 63)).astype(np.float32); trn = (-rot).copy()
+    out = [np.empty((1, M, 4), np.float32), np.empty((1, M), np.float32), np.empty((1, M), np.int32), np.empty((1, M, 3), np.float32),
+           np.empty((1, M, 3), np.float32), np.empty((1, M, 63), np.float32), np.empty((1, M), np.int32), np.empty((1,), np.int32)]
+    for specific in (0, 1):
+        _capi.check(lib.hep_set_class_specific_filter(s.handle, specific))
+        _capi.check(lib.hep_filter(s.handle, boxes.ctypes.data, cls.ctypes.data, rot.ctypes.data, trn.ctypes.data, hand.ctypes.data, 1,
+                                   ctypes.c_float(0.97), ctypes.c_float(0.5), M, *[o.ctypes.data for o in out]))
+        want = D.filter_detections(boxes[0], cls[0], rot[0], trn[0], hand[0], score_threshold=0.97, max_detections=M, class_specific_filter=bool(specific))
+        for got, w in zip(out[:7], want):
+            assert np.array_equal(got[0], w), specific
+        assert 0 < int(out[7][0]) <= M
+    assert lib.hep_set_class_specific_filter(None, 0) != 0
+    s.close()
+    # one class: the same rows in both modes
+    s1 = api["Session"](api["sd"](0, 0), 0, size, 1, "fp32")
+    t = lambda a: torch.from_numpy(a).cuda()
+    a = s1.filter(t(boxes), t(cls[:, :, :1].copy()), t(rot), t(trn), t(hand), score_threshold=0.9, max_detections=M, class_specific_filter=True)
+    b = s1.filter(t(boxes), t(cls[:, :, :1].copy()), t(rot), t(trn), t(hand), score_threshold=0.9, max_detections=M, class_specific_filter=False)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    s1.close()
 
 
 def test_module_dropin_and_pipeline(api):
