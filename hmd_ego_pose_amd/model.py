@@ -51,6 +51,7 @@ class Session:
                                                        self.device.index or 0, flags, ctypes.byref(h)))
         self.handle = h.value
         self._class_specific = True      # the handle's filter mode (hep_set_class_specific_filter)
+        self._filter_lock = threading.Lock()      # mode switch + filter call are one step for concurrent callers of one session
         self.num_anchors = _capi.lib().hep_num_anchors(self.handle)
         self.num_classes = _capi.lib().hep_num_classes(self.handle)      # read from the classifier header of the weights
         self.out_width = tuple(self.num_classes if i == 1 else k for i, k in enumerate(OUT_WIDTH))
@@ -163,13 +164,14 @@ class Session:
                    hand=f(B, M, 63), index=i(B, M), count=i(B))
         stream = torch.cuda.current_stream(dev).cuda_stream
         args = [t.contiguous() for t in (boxes, classification, rotation, translation, hand)]
-        if bool(class_specific_filter) != self._class_specific:
-            _capi.check(_capi.lib().hep_set_class_specific_filter(self.handle, int(bool(class_specific_filter))))
-            self._class_specific = bool(class_specific_filter)
-        _capi.check(_capi.lib().hep_filter_device(self.handle, *[t.data_ptr() for t in args], B, float(score_threshold),
-                                                  float(nms_threshold), M, *[out[k].data_ptr() for k in
-                                                                             ("boxes", "scores", "labels", "rotation", "translation", "hand", "index", "count")],
-                                                  stream))
+        with self._filter_lock:
+            if bool(class_specific_filter) != self._class_specific:
+                _capi.check(_capi.lib().hep_set_class_specific_filter(self.handle, int(bool(class_specific_filter))))
+                self._class_specific = bool(class_specific_filter)
+            _capi.check(_capi.lib().hep_filter_device(self.handle, *[t.data_ptr() for t in args], B, float(score_threshold),
+                                                      float(nms_threshold), M, *[out[k].data_ptr() for k in
+                                                                                 ("boxes", "scores", "labels", "rotation", "translation", "hand", "index", "count")],
+                                                      stream))
         return out
 
     # -- introspection ------------------------------------------------------------------
