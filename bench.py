@@ -627,6 +627,10 @@ def main():
                     got[d] = hd.gather_detections(det, G)
             for i in range(2 * CD):
                 serve(i)
+            # the device out of its idle power state, as for the main loop: the same number of steps on every rank (scatter and gather
+            # are collective), sized from the main loop's step time (`elapsed` is the maximum over ranks, identical everywhere)
+            for i in range(min(256, int(args.preheat_ms / max(elapsed / args.steps * 1e3, 1e-3)) + 1) if args.preheat_ms > 0 else 0):
+                serve(i)
             torch.cuda.synchronize(dev); hd.barrier()
             t1 = time.perf_counter()
             for i in range(steps):
@@ -638,7 +642,7 @@ def main():
         # (scores straddle 0.5), which times a pathological sort + NMS.  The comm loop therefore shifts the classifier
         # header's bias so that ~comm_candidates anchors per frame pass the threshold (quantile of the seeded logits on this
         # loop's own frames); the unshifted weights are reported as `pathological`.
-        k2 = max(10, args.steps // 4)
+        k2 = max(40, args.steps)          # (40 steps = 13 ms: a 10-step window scattered by +-4 %)
         x_probe = main_loop.sess[0].preprocess(frames_u8[:B] if rank == 0 else torch.zeros((B, S, S, 3), dtype=torch.uint8, device=dev))
         p = main_loop.sess[0].forward(x_probe, want_features=False)[2].float().clamp(1e-7, 1 - 1e-7)
         logit_thr = float(np.log(args.comm_score_threshold / (1 - args.comm_score_threshold)))
