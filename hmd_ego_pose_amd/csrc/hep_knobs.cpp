@@ -24,6 +24,7 @@ Knobs read_knobs() {
   env_int("HEP_PW_NT2", &k.pw_nt2);
   env_int("HEP_PW_MT2", &k.pw_mt2);
   env_int("HEP_PW_NT3", &k.pw_nt3);
+  env_int("HEP_PW_WIDE", &k.pw_wide);
   env_int("HEP_PW_W8", &k.pw_w8);
   env_int("HEP_PW_W8_MINK", &k.pw_w8_mink);
   env_int("HEP_SE_TAIL", &k.se_tail);

@@ -326,6 +326,13 @@ struct Planner {
         }
       }
     }
+    // (alt build A/B, HEP_PW_WIDE=cap: fewest column chunks - fewer, fatter workgroups, fewer copies of the squeeze-excite prologue.  Measured,
+    //  round 6: cap 8 -> 52.4k against 53.3k frames/s, with every squeeze-excite finish in the prologue 51.9k (against 50.4k with the default tiles):
+    //  a 6-7 n-tile workgroup takes 11-15 us where the 2 n-tile one takes 6)
+    if (pmode == 2 && kn.pw_wide > 0 && se) {
+      const int cap = std::min(8, kn.pw_wide), ch = (tilesN + cap - 1) / cap;
+      pNT = (tilesN + ch - 1) / ch;
+    }
     // Squeeze-excite: finished in this GEMM's prologue (no launch) while the K x sq expand-FC matrix re-read by every
     // workgroup stays below HEP_SE_MAXMB (default 4) MB per launch; beyond that a small launch finishes it once per
     // image (k_dw.hip).  Measured at phi 0, batch 16 (same box, 2 x 300 steps): threshold 1000 / 12 / 8 / 4 / 0 MB ->
@@ -386,7 +393,7 @@ struct Planner {
       // se_finish_kernel and whose activations come from a fused front (k_mbf.hip), K a multiple of the k-step, whole m-tiles per image
       int producer = -1;
       for (const Ref& r : refs) if (r.field == F_MBF_OUT && r.tensor == in_t) producer = r.op;
-      const bool frag = s->dtype != 2 && !quant_fp8 && pmode == 2 && pMT == 2 && pNT <= 4 && act != ACT_SWISH && se && HW % 16 == 0 && producer >= 0 &&
+      const bool frag = s->dtype != 2 && !quant_fp8 && pmode == 2 && pMT == 2 && pNT <= 8 && act != ACT_SWISH && se && HW % 16 == 0 && producer >= 0 &&
                         kn.pw_frag != 0;
       if (frag) {
         const int kstep = s->dtype ? 32 : 16, klane = s->dtype ? 8 : 4, kst = (K + kstep - 1) / kstep;
