@@ -771,7 +771,7 @@ int hep_kernel_symbol(const hep_handle* h, int i, const char** symbol) try {
     case OP_PW: { const int sev = pw_se_variant(o.pw);
                   const bool w8 = o.pw.nwv == 8 && prec == 0 && o.pw.mode == 2 && o.pw.act != ACT_SWISH && (sev == 0 || sev == 3) && o.pw.NT <= 2;
                   // (the names rocprofv3 prints: bench.py looks the PMC traffic of a device function up by this string)
-                  const bool fr = o.pw.frag && prec != 2 && o.pw.MT == 2 && o.pw.NT <= 8 && o.pw.mode == 2 && sev >= 1 && o.pw.act != ACT_SWISH;      // (launch_nt: fragment-ordered operands)
+                  const bool fr = o.pw.frag && prec != 2 && o.pw.MT == 2 && o.pw.NT <= PW_FRAG_MAX_NT && o.pw.mode == 2 && sev >= 1 && o.pw.act != ACT_SWISH;      // (launch_nt: fragment-ordered operands)
                   snprintf(tmp, sizeof tmp, fr ? "pw_gemm_kernel<%d, %d, %d, %d, %d, %d, %d, true>" : "pw_gemm_kernel<%d, %d, %d, %d, %d, %d, %d>", prec, o.pw.MT, o.pw.NT, o.pw.mode, o.pw.act == ACT_SWISH ? 1 : 0, sev, (w8 || (fr && o.pw.nwv == 8 && prec == 0 && sev == 3 && o.pw.NT <= 2)) ? 8 : 4); break; }
     case OP_DW: snprintf(tmp, sizeof tmp, "dw_kernel<%s, %d, %d, %d>", t, o.dw.k, o.dw.s, o.dw.TW); break;
     case OP_POOL: snprintf(tmp, sizeof tmp, "pool_kernel<%s>", t); break;

@@ -45,6 +45,14 @@ void sbf_layout(SbfArgs* a);                     // fills tiles and the LDS layo
 void launch_sbf(const SbfArgs&, hipStream_t);
 #endif
 
+// widest split-K tile (n-tiles per workgroup) the fragment-ordered GEMM is instantiated for: the planner (add_pw), the launcher (launch_nt)
+// and hep_kernel_symbol all test against THIS constant - a fragment-ordered tensor handed to a row-major instantiation would be misread
+#ifdef HEP_ALT
+constexpr int PW_FRAG_MAX_NT = 8;      // (HEP_PW_WIDE)
+#else
+constexpr int PW_FRAG_MAX_NT = 4;
+#endif
+
 // ---- pointwise conv as GEMM: out[M,N] = act((A[M,K] (*se)) . W[N,K]^T + bias) (+res) ----
 struct PwArgs {
   const void* A; const void* W; const float* bias;

@@ -393,7 +393,7 @@ struct Planner {
       // se_finish_kernel and whose activations come from a fused front (k_mbf.hip), K a multiple of the k-step, whole m-tiles per image
       int producer = -1;
       for (const Ref& r : refs) if (r.field == F_MBF_OUT && r.tensor == in_t) producer = r.op;
-      const bool frag = s->dtype != 2 && !quant_fp8 && pmode == 2 && pMT == 2 && pNT <= 8 && act != ACT_SWISH && se && HW % 16 == 0 && producer >= 0 &&
+      const bool frag = s->dtype != 2 && !quant_fp8 && pmode == 2 && pMT == 2 && pNT <= PW_FRAG_MAX_NT && act != ACT_SWISH && se && HW % 16 == 0 && producer >= 0 &&
                         kn.pw_frag != 0;
       if (frag) {
         const int kstep = s->dtype ? 32 : 16, klane = s->dtype ? 8 : 4, kst = (K + kstep - 1) / kstep;

@@ -469,7 +469,7 @@ static void launch_nt(const PwArgs& a, dim3 grid, hipStream_t s) {
     }
   }
   if constexpr (PREC != 2 && MT == 2 && MODE == 2) {
-    if (a.frag && a.act != ACT_SWISH && sev >= 1 && a.NT <= 8) {        // fragment-ordered operands (add_pw decides; hep_kernel_symbol names it)
+    if (a.frag && a.act != ACT_SWISH && sev >= 1 && a.NT <= PW_FRAG_MAX_NT) {        // fragment-ordered operands (add_pw decides; hep_kernel_symbol names it)
       if (PREC == 0 && a.nwv == 8 && sev == 3 && a.NT <= 2) {
         if (a.NT == 2) hipLaunchKernelGGL((pw_gemm_kernel<PREC, 2, 2, 2, ACT_NONE, 3, 8, true>), grid, dim3(512), lds, s, a);
         else hipLaunchKernelGGL((pw_gemm_kernel<PREC, 2, 1, 2, ACT_NONE, 3, 8, true>), grid, dim3(512), lds, s, a);
