@@ -57,6 +57,42 @@ def test_filter_fuzz_against_oracle(env):
     s.close()
 
 
+def test_best_class_filter_fuzz_against_oracle(env):
+    """class_specific_filter=False (layers.py:359-362) with three classes over candidate counts from none to every anchor (the LDS sort and,
+    at 512x512, the global-memory sort), ties between classes of one anchor (first argmax) and between anchors, every output row."""
+    Session, sd_of, D = env
+    K = 3
+    t = lambda a: torch.from_numpy(a).cuda()
+    for size in (256, 512):
+        s = Session(sd_of(0, 0, num_classes=K), 0, size, 2, "fp32")
+        N = s.num_anchors
+        rng = np.random.Generator(np.random.PCG64(900 + size))
+        for case in range(8):
+            B = int(rng.integers(1, 3))
+            ncand = int(rng.choice([0, 1, 9, 100, 2000, N]))
+            M = int(rng.choice([1, 10, 100, 256]))
+            nms = float(rng.choice([0.0, 0.5, 0.9]))
+            thr = 0.25
+            cxy = rng.uniform(20, size - 20, (B, N, 2)); wh = rng.uniform(6, 70, (B, N, 2))
+            boxes = np.concatenate([cxy - wh / 2, cxy + wh / 2], axis=2).astype(np.float32)
+            cls = rng.uniform(0, thr, (B, N, K)).astype(np.float32)
+            for b in range(B):
+                idx = rng.choice(N, min(ncand, N), replace=False)
+                sc = (rng.integers(17, 64, (len(idx), K)) / 64.0).astype(np.float32)          # 47 distinct scores: ties inside and between anchors
+                cls[b, idx] = np.where(rng.random((len(idx), K)) < 0.6, sc, cls[b, idx])
+            rot, tr = (rng.standard_normal((B, N, 3)).astype(np.float32) for _ in range(2))
+            hand = rng.standard_normal((B, N, 63)).astype(np.float32)
+            det = s.filter(t(boxes), t(cls), t(rot), t(tr), t(hand), thr, nms, M, class_specific_filter=False)
+            torch.cuda.synchronize()
+            for b in range(B):
+                o = D.filter_detections(boxes[b], cls[b], rot[b], tr[b], hand[b], thr, M, nms, class_specific_filter=False)
+                ctx = (size, case, b, ncand, M, nms)
+                for key, want in zip(("boxes", "scores", "labels", "rotation", "translation", "hand", "index"), o):
+                    assert np.array_equal(det[key][b].cpu().numpy(), want), (ctx, key)
+                assert int(det["count"][b]) == int((o[6] >= 0).sum()), ctx
+        s.close()
+
+
 @pytest.mark.parametrize("size", [256, 512])
 def test_preprocess_fuzz_against_oracle(env, size):
     Session, sd_of, D = env
