@@ -35,6 +35,7 @@ Knobs read_knobs() {
   env_int("HEP_MBF_MAXH", &k.mbf_maxh);
   if (const char* e = getenv("HEP_MBF_TS")) k.mbf_ts8 = atoi(e) == 8;
   env_int("HEP_MBF_TS16_MAXH", &k.mbf_ts16_maxh);
+  env_int("HEP_MBF_CC", &k.mbf_cc);
   env_int("HEP_MBF_MP_RES", &k.mbf_mp_res);
   env_int("HEP_DWLDS", &k.dwlds);
   env_int("HEP_LATE", &k.late);

@@ -35,6 +35,7 @@ struct Knobs {
   int mbf_maxh = 32;          // HEP_MBF_MAXH: largest input map that takes the fused front
   int mbf_ts8 = 0;            // HEP_MBF_TS=8: 8x8 tiles only
   int mbf_ts16_maxh = 32;     // HEP_MBF_TS16_MAXH
+  int mbf_cc = 64;            // HEP_MBF_CC=32|16: widest channel chunk of a fused front; -n: 32 where 64 gives <= n workgroups and 32 still <= 256 (one batch +1.1 %, four in flight -1.4 %)
   int mbf_mp_res = 0;         // HEP_MBF_MP_RES=1: multi-pass with the whole tile held in registers
   int dwlds = -1;             // HEP_DWLDS=0|1: stand-alone depthwise through LDS never / always; -1 = by shape
   int late = 0;               // HEP_LATE=1: blocks 12-15 as one image-resident launch (k_late.hip)

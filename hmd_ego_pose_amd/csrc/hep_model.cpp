@@ -597,7 +597,11 @@ struct Planner {
     const bool want = kn.mbf >= 0 ? kn.mbf == 1 : Hin <= maxh;
     if (want)
       for (int cand : {64, 32, 16})
-        if (mbf_lds_layout(b.cin, std::min(cand, b.expand ? cand : b.cexp), b.k, b.stride, s->dtype, b.expand, max_in, ts, nullptr) <= 159 * 1024) { CC = cand; break; }
+        if ((kn.mbf_cc < 0 || cand <= kn.mbf_cc) && mbf_lds_layout(b.cin, std::min(cand, b.expand ? cand : b.cexp), b.k, b.stride, s->dtype, b.expand, max_in, ts, nullptr) <= 159 * 1024) { CC = cand; break; }
+    if (kn.mbf_cc < 0 && CC == 64 && b.expand) {      // (alt build A/B: the narrower chunk where it fills one round of workgroups that the wide one leaves half empty)
+      const long tiles = (long)((Ho + ts - 1) / ts) * ((Wo + ts - 1) / ts), wg64 = tiles * ((b.cexp + 63) / 64) * s->lane_batch, wg32 = tiles * ((b.cexp + 31) / 32) * s->lane_batch;
+      if (wg64 <= -kn.mbf_cc && wg32 <= 256) CC = 32;
+    }
     // The tile / channel chunk / K-slice plan with the fewest ROUNDS of workgroups (HEP_MBF_MP=0 disables, =2 lifts the bf16
     // restriction below, =force takes the multi-pass form wherever it exists).  With the whole K staged at once an fp32 front needs twice the LDS of the bf16 one: the 16x16 tile of blocks 9,
     // 10 fell back to 8x8 (704 workgroups on 256 CUs: three rounds, 37 us against 17 us in bf16), the 8x8 maps kept one workgroup
