@@ -596,7 +596,7 @@ struct Planner {
     const int maxh = kn.mbf_maxh;     // largest input map that takes the fused front (32)
     const bool want = kn.mbf >= 0 ? kn.mbf == 1 : Hin <= maxh;
     if (want)
-      for (int cand : {64, 32, 16})
+      for (int cand : {64, 32, 16})      // (128 would need an item loop in phase C: one (pixel quad, channel quad) item per lane covers 64 channels of an 8x8 / 16x16 tile)
         if ((kn.mbf_cc < 0 || cand <= kn.mbf_cc) && mbf_lds_layout(b.cin, std::min(cand, b.expand ? cand : b.cexp), b.k, b.stride, s->dtype, b.expand, max_in, ts, nullptr) <= 159 * 1024) { CC = cand; break; }
     if (kn.mbf_cc < 0 && CC == 64 && b.expand) {      // (alt build A/B: the narrower chunk where it fills one round of workgroups that the wide one leaves half empty)
       const long tiles = (long)((Ho + ts - 1) / ts) * ((Wo + ts - 1) / ts), wg64 = tiles * ((b.cexp + 63) / 64) * s->lane_batch, wg32 = tiles * ((b.cexp + 31) / 32) * s->lane_batch;
