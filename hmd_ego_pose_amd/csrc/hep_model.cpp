@@ -316,10 +316,12 @@ struct Planner {
       {
         if (pmode != 0 && strips >= 8 && kn.pw_mt2 != 0) { pMT = 2; pNT = std::min(pNT, 4); }
         if (pmode == 2) pNT = std::min(pNT, std::max(1, kn.pw_nt2));
-        // fp32 sessions: one more n-tile per wave where that brings the launch from two rounds of workgroups to one (the last
-        // project conv of phi 0: 1152 -> 320 on the 8x8 maps, 32 x 10 = 320 workgroups with two n-tiles, 32 x 7 = 224 with three:
-        // fp32 one batch -5 us; bf16 -2 us = inside the run-to-run spread, its plan stays as it was).  (alt build: HEP_PW_NT3=0 / 1 overrides.)
-        if (pmode == 2 && (kn.pw_nt3 >= 0 ? kn.pw_nt3 != 0 : s->dtype == 0)) {
+        // One more n-tile per wave where that brings the launch from two rounds of workgroups to one (the last project conv of phi 0:
+        // 1152 -> 320 on the 8x8 maps, 32 x 10 = 320 workgroups with two n-tiles, 32 x 7 = 224 with three).  Round 4 selected it for fp32
+        // sessions (one batch -5 us); re-measured with round 6's kernels it costs throughput: fp32 four in flight 28.84k -> 29.01k frames/s
+        // WITHOUT it (four interleaved runs, one batch 17.03k -> 17.06k): the three-tile form runs four waves where the two-tile one
+        // runs eight.  Off since; alt build: HEP_PW_NT3=1 selects it.
+        if (pmode == 2 && kn.pw_nt3 > 0) {
           const int64_t mblocks = (strips + pMT - 1) / pMT;
           auto wgs = [&](int nt) { return mblocks * ((tilesN + nt - 1) / nt); };
           if (wgs(pNT) > 256 && wgs(pNT) <= 512 && pNT < 8 && wgs(pNT + 1) <= 256) pNT++;
