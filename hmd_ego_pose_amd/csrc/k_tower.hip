@@ -820,9 +820,14 @@ extern "C" int hep_dbg_tower_trace(unsigned long long* host, int max_waves, int 
 #endif
 
 void launch_tower(const SepArgs& a, hipStream_t s) {
-  // images per workgroup: amortises the weight staging; keep >= ~1000 workgroups in the launch
+  // images per workgroup: amortises descriptor, weight staging and the first halo's round trip (2 of a wave's 6 us at two images).  Headers keep
+  // >= ~900 workgroups in the launch.  Map layers >= ~400 since round 6 (phi 0 b16: 460 workgroups of four images instead of 920 of two): with
+  // the quad-form depthwise an image is 2 us of a wave, so the prologue weighs more - swept separately, sustained / one batch: maps 2 / 4 / 8 / 16
+  // images 53.29k / 53.65k / 53.67k / 53.62k and 27.79k / 27.71k / 27.27k / 25.89k; headers 1 / 2 / 4 / 8 / 16 52.45k / 53.29k / 53.20k / 53.12k / 52.77k
+  // (profiles/r06/p_tower_images_per_workgroup_sweep.txt).  Bit-identical: only the partition of the images changes.
+  const int64_t min_wgs = a.direct == 2 ? 900 : 400;
   int ipb = 1;
-  while (ipb < 4 && (int64_t)a.total_tiles * ((a.B + 2 * ipb - 1) / (2 * ipb)) >= 900) ipb *= 2;
+  while (ipb < 4 && (int64_t)a.total_tiles * ((a.B + 2 * ipb - 1) / (2 * ipb)) >= min_wgs) ipb *= 2;
   // cooperative form: the prologue (descriptor, 40 weight registers per lane, staging: 2.8 us traced) is paid per workgroup -
   // as many images as still leave ~1.5 workgroups per CU (phi 3 @ 512 b8: 8 -> 430 workgroups, 5.10k -> 5.14k frames/s; fp32 phi 0
   // b16: 4 -> 460; 8 -> 230 measured slower)
