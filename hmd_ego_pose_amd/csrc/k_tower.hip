@@ -831,7 +831,9 @@ void launch_tower(const SepArgs& a, hipStream_t s) {
   // cooperative form: the prologue (descriptor, 40 weight registers per lane, staging: 2.8 us traced) is paid per workgroup -
   // as many images as still leave ~1.5 workgroups per CU (phi 3 @ 512 b8: 8 -> 430 workgroups, 5.10k -> 5.14k frames/s; fp32 phi 0
   // b16: 4 -> 460; 8 -> 230 measured slower)
-  if (a.coop) { ipb = 8; while (ipb > 2 && (int64_t)a.total_tiles * ((a.B + ipb - 1) / ipb) < 400) ipb /= 2; }
+  // (round 6, fp32 phi 0 b16 headers: 4 -> 2 images, 460 -> 920 workgroups: 28.98k -> 29.12k frames/s; map layers 2 / 4 / 8 / 16 images
+  //  28.89k / 28.98k / 28.84k / 28.03k: four stays)
+  if (a.coop) { ipb = 8; while (ipb > 2 && (int64_t)a.total_tiles * ((a.B + ipb - 1) / ipb) < min_wgs) ipb /= 2; }
   ipb = std::min(ipb, a.B);
   const dim3 grid(a.total_tiles, (a.B + ipb - 1) / ipb);
   switch (a.C) {
