@@ -792,7 +792,8 @@ int hep_kernel_symbol(const hep_handle* h, int i, const char** symbol) try {
              else {
                const int mode = o.sep.chain ? 2 : (o.sep.nseg == 1 ? 0 : 1);
                const bool wl = o.sep.bf16 && o.sep.off_wpw && mode != 1;         // (launch_sep: staged pointwise weights)
-               snprintf(tmp, sizeof tmp, wl ? "sep_kernel<%s, %d, true>" : "sep_kernel<%s, %d, false>", t, mode);
+               if (mode == 0 && sep_w8(o.sep)) snprintf(tmp, sizeof tmp, "sep_kernel<%s, 0, false, true>", t);
+               else snprintf(tmp, sizeof tmp, wl ? "sep_kernel<%s, %d, true, false>" : "sep_kernel<%s, %d, false, false>", t, mode);
              }
              break;
   }

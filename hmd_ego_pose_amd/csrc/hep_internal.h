@@ -398,4 +398,5 @@ int filter_prepare(void);     // raises the dynamic-LDS limit of filter_kernel (
 void launch_amax_bf16(const void* x, int64_t n, unsigned* out /* float bits, zeroed */, hipStream_t);
 int dw_blocks_per_image(int Ho, int Wo, int C, int TW);
 void sep_lds_layout(int C, int bf16, int ts, int max_cols_f32, int max_cols_map, SepArgs* a, int stage_w = 0);   // stage_w: single nodes / chains of map-to-map nodes may keep their pointwise weights in LDS
+int sep_w8(const SepArgs&);   // launch_sep picks the eight-wave single-node instantiation (k_sep.hip)
 int sep_prepare(void);   // raises the dynamic-LDS limit of the sepconv kernels (call once per device)

@@ -133,9 +133,14 @@ __device__ __forceinline__ void gather_fuse(const SepSeg& sg, int b, int y, int 
 }
 
 // WL: the node's pointwise weights are staged in LDS (a.off_wpw; bf16 nodes wider than 64 channels, modes 0 / 2)
-template <bool BF16, int MODE, bool WL = false>
-__global__ __launch_bounds__(SEP_THREADS_OF(MODE, BF16), MODE == 1 ? SEP_M1_WAVES : (BF16 ? 4 : 2)) void sep_kernel(SepArgs a) {
-  constexpr int SEP_THREADS = SEP_THREADS_OF(MODE, BF16), SEP_WAVES = SEP_THREADS / 64;
+// W8: eight waves instead of sixteen for a single bf16 node of width <= 64 (round 6).  A 1024-thread workgroup at 112 VGPRs is alone on
+// its CU and spends 2.9 of its 5.4 us waiting for the fused gather; two 512-thread workgroups - of this launch or of another stream's -
+// share the CU.  Alone the launches get 0.3-1.0 us slower (6.1 / 6.8 / 7.4 -> 6.4 / 7.3 / 8.4 us), with four batches in flight
+// 53.66k -> 55.60k frames/s (+3.6 %), one batch -0.8 %, bit-identical.  (Width 160 with staged weights: 5598 -> 5376 at phi 3: stays at sixteen.)
+template <bool BF16, int MODE, bool WL = false, bool W8 = false>
+__global__ __launch_bounds__(W8 ? 512 : SEP_THREADS_OF(MODE, BF16), MODE == 1 ? SEP_M1_WAVES : (BF16 ? 4 : 2)) void sep_kernel(SepArgs a) {
+  static_assert(!W8 || (BF16 && MODE == 0 && !WL), "eight-wave form: single bf16 nodes without staged weights");
+  constexpr int SEP_THREADS = W8 ? 512 : SEP_THREADS_OF(MODE, BF16), SEP_WAVES = SEP_THREADS / 64;
   constexpr bool SINGLE = MODE == 0;
   typedef Vec8<BF16> V;
   typedef typename V::elem T;
@@ -440,7 +445,8 @@ void sep_lds_layout(int C, int bf16, int ts, int max_cols_f32, int max_cols_map,
 }
 
 int sep_prepare(void) {
-  const void* fns[8] = {reinterpret_cast<const void*>(sep_kernel<true, 0>), reinterpret_cast<const void*>(sep_kernel<true, 1>),
+  const void* fns[9] = {reinterpret_cast<const void*>(sep_kernel<true, 0, false, true>),
+                        reinterpret_cast<const void*>(sep_kernel<true, 0>), reinterpret_cast<const void*>(sep_kernel<true, 1>),
                         reinterpret_cast<const void*>(sep_kernel<true, 2>), reinterpret_cast<const void*>(sep_kernel<false, 0>),
                         reinterpret_cast<const void*>(sep_kernel<false, 1>), reinterpret_cast<const void*>(sep_kernel<false, 2>),
                         reinterpret_cast<const void*>(sep_kernel<true, 0, true>), reinterpret_cast<const void*>(sep_kernel<true, 2, true>)};
@@ -448,6 +454,9 @@ int sep_prepare(void) {
     if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024) != hipSuccess) return -1;
   return 0;
 }
+
+// single bf16 node of width <= 64 without staged weights: the eight-wave instantiation (launch_sep and hep_kernel_symbol agree through this)
+int sep_w8(const SepArgs& a) { return a.bf16 && !a.chain && a.nseg == 1 && !a.off_wpw && a.C <= 64; }
 
 void launch_sep(const SepArgs& a_, hipStream_t s) {
   const SepArgs& a = a_;
@@ -458,6 +467,7 @@ void launch_sep(const SepArgs& a_, hipStream_t s) {
     // (staged weights: every segment of the launch is a map-to-map node of the full width - the planner only sets off_wpw then)
     if (mode == 0 && a.off_wpw) hipLaunchKernelGGL((sep_kernel<true, 0, true>), grid, block, a.lds_bytes, s, a);
     else if (mode == 2 && a.off_wpw) hipLaunchKernelGGL((sep_kernel<true, 2, true>), grid, block, a.lds_bytes, s, a);
+    else if (mode == 0 && sep_w8(a)) hipLaunchKernelGGL((sep_kernel<true, 0, false, true>), grid, dim3(512), a.lds_bytes, s, a);
     else if (mode == 0) hipLaunchKernelGGL((sep_kernel<true, 0>), grid, block, a.lds_bytes, s, a);
     else if (mode == 1) hipLaunchKernelGGL((sep_kernel<true, 1>), grid, block, a.lds_bytes, s, a);
     else hipLaunchKernelGGL((sep_kernel<true, 2>), grid, block, a.lds_bytes, s, a);

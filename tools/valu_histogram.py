@@ -17,7 +17,7 @@ import sys
 import tempfile
 
 LLVM = "/opt/rocm/lib/llvm/bin"
-DEFAULT = (r"mbf_kernel<true, 5, 1, 16, false, 0>|xbf_kernel<true, 3, 2, 8, 8, [123], (32|24|288), \d+>|sep_kernel<true, 0, false>|"
+DEFAULT = (r"mbf_kernel<true, 5, 1, 16, false, 0>|xbf_kernel<true, 3, 2, 8, 8, [123], (32|24|288), \d+>|sep_kernel<true, 0, false, true>|"
            r"chain_kernel<true, 0>|pw_gemm_kernel<1, 2, 2, 2, 0, 3, 4, true>")
 
 
