@@ -368,10 +368,14 @@ int mbf_prepare(void);
 void launch_sep(const SepArgs&, hipStream_t);
 void launch_tower(const SepArgs&, hipStream_t);
 #define TOWER_BIAS_MAX 384       // bias floats staged per segment: >= 16 * n-tiles of any segment (24 map tiles, 12 per header chunk)
-// n-tiles (16 columns) per header segment of k_tower.hip; wider headers are split into segments.  As many (<= 12) as keep the
+// n-tiles (16 columns) per header segment of k_tower.hip; wider headers are split into segments.  As many as keep the
 // segment's pointwise weights in LDS (TOWER_WLDS_MAX bytes, rows padded by 16 bytes) next to the depthwise weights and the
 // operand slots: a workgroup that reads its weights from global memory re-fetches 10 x the bytes of its activations at
-// width 160 (measured at phi 3 @ 512 b8: 125 us per tower layer for 141 MB).
+// width 160 (measured at phi 3 @ 512 b8: 125 us per tower layer for 141 MB).  bf16: at most 6 since round 6 (was 12, tuned with one
+// batch in flight).  At width 64 twelve tiles are 60 KB of LDS = two 4-wave workgroups per CU for the largest streaming launch of the
+// step; six are 46 KB = three (the hand header then runs as six segments, each repeating the depthwise conv of its input).  Four
+// batches in flight, 18 / 12 / 9 / 6 / 4 / 3 tiles: 56.01k / 55.67k / 55.93k / 56.13k / 56.18k / 55.85k frames/s, one batch within 0.3 %;
+// bit-identical (profiles/r06/p_header_segment_width_sweep.txt).
 #define TOWER_WLDS_MAX (56 * 1024)
 constexpr int tower_hdr_tiles(int C, bool bf16) {
   if (!bf16) return 12;     // fp32 sessions: 12 tiles, weights from global memory where 12 tiles exceed 48 KB (staging 52 KB of them at
@@ -380,7 +384,7 @@ constexpr int tower_hdr_tiles(int C, bool bf16) {
   const long fixed = 9L * C * 4 + 4L * ks * 64 * 16;                    // depthwise weights + operand slots of the 4 waves
   const long room = TOWER_WLDS_MAX < 158L * 1024 - fixed ? TOWER_WLDS_MAX : 158L * 1024 - fixed;
   const long t = room / (16 * wp * es + 64);                            // 16 weight rows + 16 bias floats per n-tile
-  return t < 1 ? 1 : (t > 12 ? 12 : (int)t);
+  return t < 1 ? 1 : (t > 6 ? 6 : (int)t);
 }
 // ... of the cooperative form (tower_coop_kernel: a wave holds the weight fragments of its n-tiles in registers): bf16 at width 64 takes
 // a whole 567-column hand header (36 tiles, 9 per wave x 2 k-steps x 4 registers) as ONE segment - the depthwise conv of the
