@@ -377,19 +377,20 @@ void launch_tower(const SepArgs&, hipStream_t);
 // batches in flight, 18 / 12 / 9 / 6 / 4 / 3 tiles: 56.01k / 55.67k / 55.93k / 56.13k / 56.18k / 55.85k frames/s, one batch within 0.3 %;
 // bit-identical (profiles/r06/p_header_segment_width_sweep.txt).
 #define TOWER_WLDS_MAX (56 * 1024)
-constexpr int tower_hdr_tiles(int C, bool bf16) {
+constexpr int tower_hdr_tiles(int C, bool bf16, int cap = 6) {
   if (!bf16) return 12;     // fp32 sessions: 12 tiles, weights from global memory where 12 tiles exceed 48 KB (staging 52 KB of them at
                             // width 64 left one workgroup per CU: 13.7k -> 13.3k frames/s)
   const long es = bf16 ? 2 : 4, wp = C + (bf16 ? 8 : 4), kstep = bf16 ? 32 : 16, ks = (C + kstep - 1) / kstep;
   const long fixed = 9L * C * 4 + 4L * ks * 64 * 16;                    // depthwise weights + operand slots of the 4 waves
   const long room = TOWER_WLDS_MAX < 158L * 1024 - fixed ? TOWER_WLDS_MAX : 158L * 1024 - fixed;
   const long t = room / (16 * wp * es + 64);                            // 16 weight rows + 16 bias floats per n-tile
-  return t < 1 ? 1 : (t > 6 ? 6 : (int)t);
+  return t < 1 ? 1 : (t > cap ? cap : (int)t);
 }
 // ... of the cooperative form (tower_coop_kernel: a wave holds the weight fragments of its n-tiles in registers): bf16 at width 64 takes
 // a whole 567-column hand header (36 tiles, 9 per wave x 2 k-steps x 4 registers) as ONE segment - the depthwise conv of the
 // head's last map and its input are then computed / read once, not once per 12-tile chunk
-constexpr int tower_coop_hdr_tiles(int C, bool bf16) { return bf16 && C == 64 ? 36 : tower_hdr_tiles(C, bf16); }
+// (the wide bf16 layers keep segments of up to 12 tiles: with 6 phi 3 @ 512 loses 1.8 %, 5618 -> 5519 frames/s)
+constexpr int tower_coop_hdr_tiles(int C, bool bf16) { return bf16 && C == 64 ? 36 : tower_hdr_tiles(C, bf16, 12); }
 int tower_prepare(void);         // raises the dynamic-LDS limit of the tower kernels (call once per device)
 int tower_coop_supported(int C, int bf16);   // widths / dtypes tower_coop_kernel is instantiated for
 int tower_supports(int C);       // BiFPN widths k_tower.hip is instantiated for
